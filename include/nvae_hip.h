@@ -1,0 +1,218 @@
+/* nvae_hip.h -- C ABI of libnvae_hip.so: the gfx950 (MI355X) kernels behind the NVAE hot path.
+ *
+ * The reference (stevensdavid/nvae-tf) has no FFI: its hot path is Keras layers executed by the
+ * TensorFlow runtime.  Each entry point below therefore cites the reference Python call site whose
+ * arithmetic it replaces (file:line under the reference root).  INTEGRATION.md shows the ctypes
+ * binding a maintainer would add.
+ *
+ * Conventions
+ *  - plain pointers and sizes only; all pointers are DEVICE pointers unless stated otherwise;
+ *  - activations are NHWC, contiguous in C, element type `dtype` (NVAE_F32 / NVAE_BF16);
+ *    statistics, losses, master weights, gradients of weights and optimizer slots are always f32;
+ *  - every call enqueues on `stream` (a hipStream_t passed as void*) and never synchronises,
+ *    allocates or frees, so a sequence of calls can be captured into a hipGraph;
+ *  - buffers documented "zeroed" must be zero when the call is enqueued (they are accumulated
+ *    into with atomics);
+ *  - return value: NVAE_OK, or an error code with a message available from nvae_last_error().
+ *    Inputs are borrowed, outputs are caller-allocated.  Entry points are thread-safe (no global
+ *    mutable state except the thread-local error string).
+ */
+#ifndef NVAE_HIP_H
+#define NVAE_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NVAE_OK 0
+#define NVAE_EINVAL 1   /* bad argument / unsupported shape */
+#define NVAE_ELAUNCH 2  /* HIP launch failure */
+
+#define NVAE_F32 0
+#define NVAE_BF16 1
+
+#define NVAE_ACT_NONE 0
+#define NVAE_ACT_SWISH 1
+#define NVAE_ACT_ELU 2
+
+#define NVAE_OP_AFFINE 0 /* y = a*x + b   (preprocess.py:39, `2 * inputs - 1`) */
+#define NVAE_OP_SWISH 1  /* activations.swish (preprocess.py:66) */
+#define NVAE_OP_ELU 2    /* layers.ELU (common.py:54, encoder.py:60-65, postprocess.py:27) */
+
+const char* nvae_last_error(void);
+int nvae_abi_version(void);
+
+/* Geometry of one convolution-shaped gather GEMM.
+ *   out[b, ho, wo, n] = sum_{kh,kw,c} src[b, hs, ws, c] * w[(kh,kw,c), n]
+ *   hc = ho*stride - pad_t + kh;  valid iff 0 <= hc < Hin*div and (!exact || hc % div == 0);
+ *   hs = hc / div                                   (same for the w axis)
+ * Forward conv:       div = nearest-upsample factor (1 or 2), exact = 0, stride = conv stride.
+ * Data gradient:      src = dy, stride = 1, div = forward stride, exact = 1, pad = K-1-pad_fwd,
+ *                     weights tap-flipped and transposed (see nvae_weight_prep).
+ * TF 'same' padding is expressed by the caller through pad_t/pad_l (may be negative).         */
+typedef struct NvaeConvGeom {
+    int B, Hin, Win, Cin;    /* source tensor; Cin = channels contracted                       */
+    int Hout, Wout, Cout;    /* output tensor                                                   */
+    int KH, KW;
+    int stride, pad_t, pad_l;
+    int div, exact;
+    int in_ld, out_ld, res_ld; /* pixel strides (elements) of src / out / residual             */
+} NvaeConvGeom;
+
+/* ---- dense convolutions: Conv2D call sites preprocess.py:19-23,92-99 encoder.py:92-98,12,47-57,61
+ *      decoder.py:110-112,126-134 postprocess.py:29,78-82,96-105 common.py:41-62,150-163 ------ */
+/* MFMA implicit GEMM.  wT: [Cout][w_ld] (k contiguous, k = (kh*KW+kw)*Cin + c), element type
+ * `dtype`.  bias (f32, may be NULL), residual (dtype, may be NULL; may alias out = accumulate).
+ * Requires Cin, in_ld, w_ld multiples of 8 (bf16) / 4 (f32) and 16-B aligned src/wT.            */
+int nvae_conv_gemm(int dtype, const NvaeConvGeom* g, const void* src, const void* wT, int w_ld,
+                   const float* bias, const void* residual, void* out, int out_f32, void* stream);
+/* Weight gradient: dw[k, n] += sum_m gather(x)[m, k] * dy[m, n]  (f32 atomics, dw zeroed or
+ * holding a partial sum).  g describes the FORWARD conv; dy has pixel stride g->out_ld.
+ * dw_ld = row stride of dw in floats.                                                          */
+int nvae_conv_wgrad(int dtype, const NvaeConvGeom* g, const void* x, const void* dy, float* dw,
+                    int dw_ld, void* stream);
+/* Scalar fallback for shapes the MFMA path does not take (Cin = 1, 20; Cout = 1).  w is the f32
+ * master [KH, KW, *, *] addressed as w[tap*ws_tap + c*ws_c + n*ws_n] (tap order flipped if
+ * flip != 0), so the same kernel serves forward and data-gradient.                              */
+int nvae_conv_direct(int dtype, const NvaeConvGeom* g, const void* src, const float* w, long ws_tap,
+                     long ws_c, long ws_n, int flip, const float* bias, const void* residual,
+                     void* out, int out_f32, void* stream);
+/* dw[(tap*Cin + c)*dw_ld + n] += ..., db[n] += sum_m dy[m, n] (db may be NULL).                 */
+int nvae_conv_direct_wgrad(int dtype, const NvaeConvGeom* g, const void* x, const void* dy,
+                           float* dw, int dw_ld, float* db, void* stream);
+/* out[c] += sum_r x[r*ld + c]  (bias gradients).  C multiple of 8.                              */
+int nvae_colsum(int dtype, const void* x, long rows, int C, int ld, float* out, void* stream);
+
+/* ---- DepthwiseConv2D((5,5), 'same'), decoder.py:130.  w f32 [5,5,C], bias f32 or NULL.
+ *      flip=1 gives the data gradient.                                                         */
+int nvae_dwconv5(int dtype, const void* x, const float* w, const float* bias, void* y, int B, int H,
+                 int W, int C, int flip, int accumulate, void* stream);
+int nvae_dwconv5_wgrad(int dtype, const void* x, const void* dy, float* dw, float* db, int B, int H,
+                       int W, int C, void* stream);
+
+/* ---- BatchNormalization(momentum=.05, eps=1e-5) (+Swish), encoder.py:91-103, decoder.py:125-146,
+ *      postprocess.py:71,84,107-108, preprocess.py:88-89, common.py:148,165-166 ------------------- */
+int nvae_bn_stats(int dtype, const void* x, long rows, int C, float* sums /*[2C] zeroed*/, void* stream);
+/* mean/var from sums; scale = gamma*invstd, shift = beta - mean*scale; moving stats updated with
+ * Keras semantics: moving = moving*momentum + batch*(1-momentum).                               */
+int nvae_bn_finalize(const float* sums, long rows, int C, const float* gamma, const float* beta,
+                     float* running_mean, float* running_var, float momentum, float eps,
+                     float* scale, float* shift, float* mean, float* invstd, void* stream);
+int nvae_bn_eval_prepare(const float* gamma, const float* beta, const float* running_mean,
+                         const float* running_var, int C, float eps, float* scale, float* shift,
+                         void* stream);
+int nvae_bn_apply(int dtype, const void* x, void* y, long rows, int C, const float* scale,
+                  const float* shift, int act, void* stream);
+/* dgamma/dbeta (f32, zeroed) receive sum(dpre * xhat), sum(dpre); dpre = dy * act'(pre).        */
+int nvae_bn_bwd_reduce(int dtype, const void* x, const void* dy, long rows, int C, const float* scale,
+                       const float* shift, const float* mean, const float* invstd, int act,
+                       float* dgamma, float* dbeta, void* stream);
+int nvae_bn_bwd_apply(int dtype, const void* x, const void* dy, void* dx, long rows, int C,
+                      const float* scale, const float* shift, const float* mean, const float* invstd,
+                      int act, const float* dgamma, const float* dbeta, int accumulate, void* stream);
+
+/* ---- SqueezeExcitation + residual, common.py:127-142 with encoder.py:107 / decoder.py:147 /
+ *      preprocess.py:107 / postprocess.py:58:   y = skip_scale*skip + branch_scale*(x * gate) ----- */
+int nvae_se_pool(int dtype, const void* x, int B, int HW, int C, float* pooled_sum /*[B,C] zeroed*/,
+                 void* stream);
+int nvae_se_gate(const float* pooled_sum, int B, int HW, int C, int Hd, const float* w1,
+                 const float* b1, const float* w2, const float* b2, float* gate, float* hidden,
+                 void* stream);
+int nvae_se_apply(int dtype, const void* x, const void* skip, void* y, int B, int HW, int C,
+                  const float* gate, float skip_scale, float branch_scale, void* stream);
+int nvae_se_bwd_reduce(int dtype, const void* x, const void* dy, int B, int HW, int C,
+                       float* r /*[B,C] zeroed*/, void* stream);
+int nvae_se_gate_bwd(const float* r, const float* pooled_sum, const float* gate, const float* hidden,
+                     int B, int HW, int C, int Hd, const float* w1, const float* w2, float branch_scale,
+                     float* dw1, float* db1, float* dw2, float* db2, float* dpool, void* stream);
+int nvae_se_bwd_apply(int dtype, const void* dy, const float* gate, const float* dpool, void* dx,
+                      void* dskip, int B, int HW, int C, float skip_scale, float branch_scale,
+                      int acc_dx, int acc_dskip, void* stream);
+
+/* ---- elementwise ------------------------------------------------------------------------- */
+int nvae_unary_fwd(int dtype, int op, const void* x, void* y, long n, float a, float b, void* stream);
+int nvae_unary_bwd(int dtype, int op, const void* x, const void* dy, void* dx, long n, int accumulate,
+                   void* stream);
+int nvae_add(int dtype, void* dst, const void* src, long n, int accumulate, void* stream);
+int nvae_cast(int src_dtype, int dst_dtype, const void* src, void* dst, long n, void* stream);
+/* backward of tf.image.resize(nearest, xf) (common.py:168-172): dx = sum over fxf blocks        */
+int nvae_upsample_pool_bwd(int dtype, const void* dxu, void* dx, int B, int H, int W, int C, int f,
+                           int accumulate, void* stream);
+/* eps ~ N(0,1): Philox4x32-10 + Box-Muller, counter read from / advanced in device memory so
+ * the call is graph-replayable (common.py:67 tf.random.normal).                                 */
+int nvae_randn(float* out, long n, unsigned long long seed, unsigned long long* counter_dev,
+               void* stream);
+
+/* ---- Sampler.call + KL term + log q / log p, common.py:76-102, models.py:197-201,
+ *      util.py:39-50, decoder.py:69-71,84-90.  enc_p / dec_p: f32 [B,HW,2L] raw conv outputs
+ *      (dec_p NULL for group 0), eps f32 [B,HW,L].  z: dtype.  kl: f32 [B].  logq/logp: f32 [B]
+ *      accumulated (+=) when non-NULL.  mu_sigma (f32 [4,B,HW,L], may be NULL) receives
+ *      enc_mu, enc_sigma, dec_mu, dec_sigma for DistributionParams.                            */
+int nvae_sampler_fwd(int dtype, const float* enc_p, const float* dec_p, const float* eps, void* z,
+                     float* kl, float* logq, float* logp, float* mu_sigma, int B, int HW, int L,
+                     void* stream);
+/* d_enc/d_dec (dtype) = gradient wrt the raw conv outputs, given dz (dtype, may be NULL) and
+ * dL/dKL[b] = hyper[NVAE_HY_BETA] * coeff[0] * inv_batch.                                       */
+int nvae_sampler_bwd(int dtype, const float* enc_p, const float* dec_p, const float* eps,
+                     const void* dz, const float* coeff, const float* hyper, float inv_batch,
+                     void* d_enc, void* d_dec, int B, int HW, int L, void* stream);
+
+/* ---- Bernoulli reconstruction, models.py:242-250: recon[b] = sum softplus(l) - x*l;
+ *      crop != 0 restricts to rows/cols [2, H-2) (evaluate.py:117).  logits f32, x dtype.        */
+int nvae_bernoulli_fwd(int dtype, const float* logits, const void* x, float* recon, int B, int H,
+                       int W, int C, int crop, void* stream);
+int nvae_bernoulli_bwd(int dtype, const float* logits, const void* x, void* dlogits, long n,
+                       float inv_batch, void* stream);
+
+/* ---- KL balancing + loss assembly, models.py:121-126, 204-222 ------------------------------ */
+#define NVAE_HY_LR 0       /* lr / (1 - beta1^t)                       */
+#define NVAE_HY_BETA 1     /* KL warm-up coefficient (models.py:122)   */
+#define NVAE_HY_BALANCE 2  /* 1.0 if beta < 1 (models.py:123)          */
+#define NVAE_HY_SIZE 8
+#define NVAE_RES_LOSS 0
+#define NVAE_RES_BN 1
+#define NVAE_RES_RECON 2   /* mean_b recon     */
+#define NVAE_RES_KL 3      /* mean_b beta*KL   */
+#define NVAE_RES_SIZE 8
+/* am[g] = mean_b |kl_all[g,b]|  (all-reduce-averaged across ranks by the caller when DP)         */
+int nvae_kl_absmean(const float* kl_all, int G, int B, float* am, void* stream);
+int nvae_loss_finalize(const float* kl_all, const float* am, const float* alphas, int G, int B,
+                       const float* recon, const float* bn_loss, const float* hyper, float* coeff,
+                       float* kl_loss, float* results, void* stream);
+/* calculate_bn_loss, models.py:252-267.  table: int32 [n_layers,2] = (offset of gamma in the flat
+ * parameter buffer, C).                                                                         */
+int nvae_bn_absmax_fwd(const float* params, const int* table, int n_layers, float lambda,
+                       float* bn_loss /*zeroed*/, int* argmax, void* stream);
+int nvae_bn_absmax_bwd(const float* params, float* grads, const int* table, const int* argmax,
+                       int n_layers, float lambda, void* stream);
+
+/* ---- Adamax (train.py:131; Keras defaults) over a flat buffer ------------------------------ */
+int nvae_adamax(float* p, const float* g, float* m, float* u, long n, const float* hyper, float beta1,
+                float beta2, float eps, void* stream);
+
+/* ---- SpectralNormalization (TFA) power iteration + compute-copy preparation.
+ *      One descriptor per wrapped conv; all offsets are element offsets into flat buffers.      */
+typedef struct NvaeConvDesc {
+    long long w_off;   /* master f32 [KH,KW,Cin,Cout] in `params`                                */
+    long long wf_off;  /* forward copy  [Cout][wf_ld]   in `wcopies` (dtype)                      */
+    long long wd_off;  /* dgrad copy    [Cin][wd_ld], taps flipped, in `wcopies`; -1 = none       */
+    int u_off;         /* u [Cout] in `sn_state`                                                 */
+    int t_off;         /* scratch t [K] in `sn_scratch`                                          */
+    int K, Cout, Cin, taps;
+    int wf_ld, wd_ld;
+    int idx;           /* position in per-matrix scratch arrays                                  */
+    int blk_off;       /* first workgroup of this matrix; a workgroup owns 16 consecutive k rows  */
+} NvaeConvDesc;
+/* One power iteration per matrix: v = l2n(u W^T); u' = l2n(v W); sigma = v W u'^T.  Writes u' into
+ * sn_state and 1/sigma into inv_sigma; W itself is rescaled by nvae_weight_prep.                 */
+int nvae_sn_power_iter(float* params, const NvaeConvDesc* descs /*device*/, int n, int total_blocks,
+                       float* sn_state, float* sn_scratch_t, float* nt2 /*[n] zeroed*/,
+                       float* w2 /*[sum Cout] zeroed*/, float* inv_sigma /*[n]*/, void* stream);
+/* W *= inv_sigma[i] in place (skipped if inv_sigma NULL) and (re)write both compute copies.      */
+int nvae_weight_prep(int dtype, float* params, const NvaeConvDesc* descs, int n, int total_blocks,
+                     const float* inv_sigma, void* wcopies, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

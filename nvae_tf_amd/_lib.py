@@ -1,0 +1,130 @@
+"""ctypes binding of libnvae_hip.so (include/nvae_hip.h).
+
+The product path has no CPU fallback: importing this module without a built library, or calling
+an entry point that fails, raises.  PyTorch is used only as the owner of device memory and streams:
+tensors are passed as raw device pointers, the current torch stream as a hipStream_t."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libnvae_hip.so")
+
+F32, BF16 = 0, 1
+ACT_NONE, ACT_SWISH, ACT_ELU = 0, 1, 2
+OP_AFFINE, OP_SWISH, OP_ELU = 0, 1, 2
+HY_LR, HY_BETA, HY_BALANCE, HY_SIZE = 0, 1, 2, 8
+RES_LOSS, RES_BN, RES_RECON, RES_KL, RES_SIZE = 0, 1, 2, 3, 8
+
+
+class ConvGeom(C.Structure):
+    _fields_ = [(n, C.c_int) for n in
+                ("B", "Hin", "Win", "Cin", "Hout", "Wout", "Cout", "KH", "KW", "stride", "pad_t",
+                 "pad_l", "div", "exact", "in_ld", "out_ld", "res_ld")]
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [("w_off", C.c_longlong), ("wf_off", C.c_longlong), ("wd_off", C.c_longlong),
+                ("u_off", C.c_int), ("t_off", C.c_int), ("K", C.c_int), ("Cout", C.c_int),
+                ("Cin", C.c_int), ("taps", C.c_int), ("wf_ld", C.c_int), ("wd_ld", C.c_int),
+                ("idx", C.c_int), ("blk_off", C.c_int)]
+
+
+_p, _i, _l, _f = C.c_void_p, C.c_int, C.c_long, C.c_float
+_G = C.POINTER(ConvGeom)
+
+# name -> argtypes (the trailing stream argument is appended automatically)
+_SIGS = {
+    "nvae_conv_gemm": [_i, _G, _p, _p, _i, _p, _p, _p, _i],
+    "nvae_conv_wgrad": [_i, _G, _p, _p, _p, _i],
+    "nvae_conv_direct": [_i, _G, _p, _p, _l, _l, _l, _i, _p, _p, _p, _i],
+    "nvae_conv_direct_wgrad": [_i, _G, _p, _p, _p, _i, _p],
+    "nvae_colsum": [_i, _p, _l, _i, _i, _p],
+    "nvae_dwconv5": [_i, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i],
+    "nvae_dwconv5_wgrad": [_i, _p, _p, _p, _p, _i, _i, _i, _i],
+    "nvae_bn_stats": [_i, _p, _l, _i, _p],
+    "nvae_bn_finalize": [_p, _l, _i, _p, _p, _p, _p, _f, _f, _p, _p, _p, _p],
+    "nvae_bn_eval_prepare": [_p, _p, _p, _p, _i, _f, _p, _p],
+    "nvae_bn_apply": [_i, _p, _p, _l, _i, _p, _p, _i],
+    "nvae_bn_bwd_reduce": [_i, _p, _p, _l, _i, _p, _p, _p, _p, _i, _p, _p],
+    "nvae_bn_bwd_apply": [_i, _p, _p, _p, _l, _i, _p, _p, _p, _p, _i, _p, _p, _i],
+    "nvae_se_pool": [_i, _p, _i, _i, _i, _p],
+    "nvae_se_gate": [_p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p],
+    "nvae_se_apply": [_i, _p, _p, _p, _i, _i, _i, _p, _f, _f],
+    "nvae_se_bwd_reduce": [_i, _p, _p, _i, _i, _i, _p],
+    "nvae_se_gate_bwd": [_p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _f, _p, _p, _p, _p, _p],
+    "nvae_se_bwd_apply": [_i, _p, _p, _p, _p, _p, _i, _i, _i, _f, _f, _i, _i],
+    "nvae_unary_fwd": [_i, _i, _p, _p, _l, _f, _f],
+    "nvae_unary_bwd": [_i, _i, _p, _p, _p, _l, _i],
+    "nvae_add": [_i, _p, _p, _l, _i],
+    "nvae_cast": [_i, _i, _p, _p, _l],
+    "nvae_upsample_pool_bwd": [_i, _p, _p, _i, _i, _i, _i, _i, _i],
+    "nvae_randn": [_p, _l, C.c_ulonglong, _p],
+    "nvae_sampler_fwd": [_i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i],
+    "nvae_sampler_bwd": [_i, _p, _p, _p, _p, _p, _p, _f, _p, _p, _i, _i, _i],
+    "nvae_bernoulli_fwd": [_i, _p, _p, _p, _i, _i, _i, _i, _i],
+    "nvae_bernoulli_bwd": [_i, _p, _p, _p, _l, _f],
+    "nvae_kl_absmean": [_p, _i, _i, _p],
+    "nvae_loss_finalize": [_p, _p, _p, _i, _i, _p, _p, _p, _p, _p, _p],
+    "nvae_bn_absmax_fwd": [_p, _p, _i, _f, _p, _p],
+    "nvae_bn_absmax_bwd": [_p, _p, _p, _p, _i, _f],
+    "nvae_adamax": [_p, _p, _p, _p, _l, _p, _f, _f, _f],
+    "nvae_sn_power_iter": [_p, _p, _i, _i, _p, _p, _p, _p, _p],
+    "nvae_weight_prep": [_i, _p, _p, _i, _i, _p, _p],
+}
+EXPORTS = ["nvae_last_error", "nvae_abi_version", *_SIGS.keys()]
+
+_lib = None
+
+
+def load():
+    """Load the shared library (raises if it has not been built)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: run `python -m nvae_tf_amd.build` (hipcc, gfx950). "
+            "There is no CPU fallback for the NVAE hot path.")
+    lib = C.CDLL(LIB_PATH)
+    lib.nvae_last_error.restype = C.c_char_p
+    lib.nvae_last_error.argtypes = []
+    lib.nvae_abi_version.restype = C.c_int
+    for name, sig in _SIGS.items():
+        fn = getattr(lib, name)
+        fn.restype = C.c_int
+        fn.argtypes = [*sig, _p]
+    _lib = lib
+    return lib
+
+
+def ptr(t):
+    """Raw device pointer of a tensor (None -> NULL)."""
+    if t is None:
+        return None
+    if isinstance(t, int):
+        return t
+    return t.data_ptr()
+
+
+def stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def call(name: str, *args):
+    """Invoke an entry point on the current torch stream; raise on a non-zero return code."""
+    lib = load()
+    rc = getattr(lib, name)(*args, stream())
+    if rc != 0:
+        raise RuntimeError(f"{name} failed (code {rc}): {lib.nvae_last_error().decode()}")
+
+
+def dtype_code(dt: torch.dtype) -> int:
+    if dt == torch.float32:
+        return F32
+    if dt == torch.bfloat16:
+        return BF16
+    raise ValueError(f"unsupported activation dtype {dt}")

@@ -1,0 +1,139 @@
+// Shared device helpers for the NVAE gfx950 kernels.  CDNA4 only: wave64, MFMA, 160 KB LDS.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include "../../include/nvae_hip.h"
+
+typedef __bf16 bf16;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+extern thread_local char g_nvae_err[512];
+
+#define NVAE_FAIL(code, ...)                                   \
+    do {                                                       \
+        snprintf(g_nvae_err, sizeof(g_nvae_err), __VA_ARGS__); \
+        return (code);                                         \
+    } while (0)
+
+#define NVAE_REQUIRE(cond, ...)                                \
+    do {                                                       \
+        if (!(cond)) NVAE_FAIL(NVAE_EINVAL, __VA_ARGS__);      \
+    } while (0)
+
+#define NVAE_LAUNCH_CHECK(name)                                                            \
+    do {                                                                                   \
+        hipError_t e_ = hipGetLastError();                                                 \
+        if (e_ != hipSuccess) NVAE_FAIL(NVAE_ELAUNCH, "%s: %s", name, hipGetErrorString(e_)); \
+    } while (0)
+
+static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// ---------------------------------------------------------------------------------------
+// 8-element vector access: one 16-B access for bf16, two for f32.
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ float bf2f(unsigned short h) { return __uint_as_float(((unsigned)h) << 16); }
+__device__ __forceinline__ unsigned short f2bf(float f) {
+    bf16 b = (bf16)f;   // v_cvt_pk_bf16_f32: RNE, NaN-preserving
+    return __builtin_bit_cast(unsigned short, b);
+}
+
+template <typename T> struct V8;
+template <> struct V8<float> {
+    static __device__ __forceinline__ void ld(const float* p, float (&v)[8]) {
+        float4 a = ((const float4*)p)[0], b = ((const float4*)p)[1];
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    }
+    static __device__ __forceinline__ void st(float* p, const float (&v)[8]) {
+        ((float4*)p)[0] = make_float4(v[0], v[1], v[2], v[3]);
+        ((float4*)p)[1] = make_float4(v[4], v[5], v[6], v[7]);
+    }
+};
+template <> struct V8<bf16> {
+    static __device__ __forceinline__ void ld(const bf16* p, float (&v)[8]) {
+        uint4 r = *(const uint4*)p;
+        v[0] = __uint_as_float(r.x << 16); v[1] = __uint_as_float(r.x & 0xffff0000u);
+        v[2] = __uint_as_float(r.y << 16); v[3] = __uint_as_float(r.y & 0xffff0000u);
+        v[4] = __uint_as_float(r.z << 16); v[5] = __uint_as_float(r.z & 0xffff0000u);
+        v[6] = __uint_as_float(r.w << 16); v[7] = __uint_as_float(r.w & 0xffff0000u);
+    }
+    static __device__ __forceinline__ void st(bf16* p, const float (&v)[8]) {
+        uint4 r;
+        r.x = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
+        r.y = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
+        r.z = (unsigned)f2bf(v[4]) | ((unsigned)f2bf(v[5]) << 16);
+        r.w = (unsigned)f2bf(v[6]) | ((unsigned)f2bf(v[7]) << 16);
+        *(uint4*)p = r;
+    }
+};
+
+template <typename T> __device__ __forceinline__ float ldf(const T* p);
+template <> __device__ __forceinline__ float ldf<float>(const float* p) { return *p; }
+template <> __device__ __forceinline__ float ldf<bf16>(const bf16* p) { return (float)*p; }
+template <typename T> __device__ __forceinline__ void stf(T* p, float v);
+template <> __device__ __forceinline__ void stf<float>(float* p, float v) { *p = v; }
+template <> __device__ __forceinline__ void stf<bf16>(bf16* p, float v) { *p = (bf16)v; }
+
+// ---------------------------------------------------------------------------------------
+// math
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float swishf_(float x) { return x * sigmoidf_(x); }
+__device__ __forceinline__ float dswishf_(float x) {
+    float s = sigmoidf_(x);
+    return s * (1.0f + x * (1.0f - s));
+}
+__device__ __forceinline__ float eluf_(float x) { return x > 0.f ? x : expm1f(x); }
+__device__ __forceinline__ float deluf_(float x) { return x > 0.f ? 1.f : __expf(x); }
+__device__ __forceinline__ float softplusf_(float x) {
+    return fmaxf(x, 0.f) + log1pf(__expf(-fabsf(x)));
+}
+
+// wave64 reductions
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+// block (256 threads) sum via LDS; result valid in every thread
+__device__ __forceinline__ float block_sum256(float v, float* sm /* >= 4 floats */) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return sm[0] + sm[1] + sm[2] + sm[3];
+}
+
+// exact unsigned division by a runtime constant: q = (n * M) >> 40, valid for n < 2^40 / d
+struct FastDiv {
+    unsigned long long M;
+    unsigned d;
+};
+static inline FastDiv make_fastdiv(unsigned d) {
+    FastDiv f;
+    f.d = d;
+    f.M = ((1ull << 40) / d) + 1;
+    return f;
+}
+__device__ __forceinline__ unsigned fdiv(unsigned n, const FastDiv& f) {
+    return (unsigned)(((unsigned long long)n * f.M) >> 40);
+}
+
+// Activation codes shared with the host
+#define ACT_NONE 0
+#define ACT_SWISH 1
+#define ACT_ELU 2
+
+#define DISPATCH_T(dtype, ...)                                        \
+    if ((dtype) == NVAE_F32) { typedef float T; __VA_ARGS__ }         \
+    else if ((dtype) == NVAE_BF16) { typedef bf16 T; __VA_ARGS__ }    \
+    else NVAE_FAIL(NVAE_EINVAL, "bad dtype %d", (int)(dtype));

@@ -1,0 +1,466 @@
+// MFMA implicit-GEMM convolutions for gfx950: forward / data-gradient (k_conv_gemm) and
+// weight-gradient (k_conv_wgrad).  bf16 inputs use v_mfma_f32_16x16x32_bf16, f32 inputs use the
+// exact v_mfma_f32_16x16x4_f32; both accumulate in f32 and share one C/D fragment map
+// (col = lane & 15, row = 4*(lane >> 4) + reg).
+//
+// k_conv_gemm:  C[M, N] = A[M, K] * B[K, N],  M = B*Hout*Wout, K = KH*KW*Cin, N = Cout.
+//   A is gathered on the fly from the NHWC source (TF-'same' padding, stride, nearest-upsample or
+//   gradient dilation are all folded into the gather, see NvaeConvGeom); B comes pre-transposed
+//   ([N][K], k contiguous) so both LDS tiles are [rows][4 x 16-B chunks] and every MFMA operand is
+//   one ds_read_b128.  The tile is 128 x BN x (4 chunks), 4 waves as 2 x 2, LDS double-buffered with
+//   one barrier per K-step; the global loads of step t+1 are in flight behind the MFMAs of step t.
+//   LDS chunk slots are XOR-swizzled (slot = chunk ^ f(row), f = {0,2,3,1}[(row>>2)&3]), which makes
+//   the 16x16x32 operand read conflict-free over the hardware's 16-lane ds_read_b128 groups.
+//   Workgroups are renumbered so that each XCD owns a contiguous range of tiles (the N-tiles of one
+//   M-tile, and neighbouring M-tiles, share gathered activations and weight panels through that L2).
+//
+// k_conv_wgrad: dW[K, N] += A^T[K, M] * dY[M, N].  Both operands arrive pixel-major ([m][channels],
+//   the natural NHWC order), are staged as such, and are transposed for free by ds_read_b64_tr_b16
+//   (bf16) when the fragments are read.  The reduction over M is split across blockIdx.y and
+//   combined with f32 atomics into the (zeroed) flat gradient buffer.
+#include "common.h"
+
+template <typename T> struct Tr;
+template <> struct Tr<bf16> { static constexpr int VE = 8; };
+template <> struct Tr<float> { static constexpr int VE = 4; };
+
+__device__ __forceinline__ int swz4(int row) { return (0x1320 >> (((row >> 2) & 3) * 4)) & 3; }
+
+// bijective XCD remap (cdna guide T1): consecutive logical tiles land on one XCD
+__device__ __forceinline__ int xcd_remap(int id, int n) {
+    int q = n >> 3, r = n & 7, x = id & 7, l = id >> 3;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + l;
+}
+
+template <typename T>
+__device__ __forceinline__ void mfma_step(const uint4& a, const uint4& b, f32x4& acc) {
+    if constexpr (sizeof(T) == 2) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a),
+                                                      __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
+    } else {
+        // the lane's 16-B chunk holds 4 consecutive k; A and B use the same k permutation
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.x), __uint_as_float(b.x), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.y), __uint_as_float(b.y), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.z), __uint_as_float(b.z), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.w), __uint_as_float(b.w), acc, 0, 0, 0);
+    }
+}
+
+template <typename T, int BN>
+__global__ __launch_bounds__(256, 2) void k_conv_gemm(NvaeConvGeom g, const T* __restrict__ src,
+                                                      const T* __restrict__ wT, int w_ld,
+                                                      const float* __restrict__ bias, const T* residual,
+                                                      void* out, int out_f32, int M, int K, int n_tiles,
+                                                      int total_tiles, FastDiv fd_hw, FastDiv fd_w) {
+    constexpr int BM = 128;
+    constexpr int VE = Tr<T>::VE;
+    constexpr int BKE = 4 * VE;
+    constexpr int NI = BN / 32;        // 16-wide n blocks per wave
+    constexpr int BCH = BN / 64;       // B chunks per thread
+    __shared__ uint4 lds[2][(BM + BN) * 4];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tile = xcd_remap(blockIdx.x, total_tiles);
+    const int bm = tile / n_tiles, bn = tile - bm * n_tiles;
+    const int N = g.Cout;
+
+    // ---- per-thread gather state -------------------------------------------------------
+    const int slot = tid & 3, row0 = tid >> 2;
+    const int kc = (slot ^ swz4(row0)) * VE;       // this thread's element offset inside a K-step
+    int tap = kc / g.Cin;
+    int ci = kc - tap * g.Cin;
+    int kh = tap / g.KW, kw = tap - kh * g.KW;
+    int kabs = kc;
+    const int hlim = g.Hin * g.div, wlim = g.Win * g.div;
+
+    int hb[2], wb[2];
+    long pb[2];
+    bool mv[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        int m = bm * BM + row0 + 64 * i;
+        mv[i] = m < M;
+        unsigned mm = mv[i] ? (unsigned)m : 0u;
+        unsigned b = fdiv(mm, fd_hw);
+        unsigned rem = mm - b * fd_hw.d;
+        unsigned ho = fdiv(rem, fd_w);
+        unsigned wo = rem - ho * fd_w.d;
+        hb[i] = (int)ho * g.stride - g.pad_t;
+        wb[i] = (int)wo * g.stride - g.pad_l;
+        pb[i] = (long)b * g.Hin * g.Win;
+    }
+    const T* bp[BCH];
+    bool nv[BCH];
+#pragma unroll
+    for (int j = 0; j < BCH; ++j) {
+        int n = bn * BN + row0 + 64 * j;
+        nv[j] = n < N;
+        bp[j] = wT + (long)(nv[j] ? n : 0) * w_ld;
+    }
+
+    uint4 ra[2], rb[BCH];
+    auto load_step = [&]() {
+        const bool kval = kabs < K;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            int hc = hb[i] + kh, wc = wb[i] + kw;
+            bool ok = mv[i] && kval && hc >= 0 && hc < hlim && wc >= 0 && wc < wlim;
+            int hs = hc, ws = wc;
+            if (g.div != 1) {
+                hs = hc / g.div; ws = wc / g.div;
+                if (g.exact) ok = ok && (hs * g.div == hc) && (ws * g.div == wc);
+            }
+            ra[i] = make_uint4(0, 0, 0, 0);
+            if (ok) ra[i] = *(const uint4*)(src + (pb[i] + (long)hs * g.Win + ws) * g.in_ld + ci);
+        }
+#pragma unroll
+        for (int j = 0; j < BCH; ++j) {
+            rb[j] = make_uint4(0, 0, 0, 0);
+            if (nv[j] && kval) rb[j] = *(const uint4*)(bp[j] + kabs);
+        }
+        kabs += BKE;
+        ci += BKE;
+        while (ci >= g.Cin) {
+            ci -= g.Cin;
+            if (++kw == g.KW) { kw = 0; ++kh; }
+        }
+    };
+
+    f32x4 acc[4][NI];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int nk = (K + BKE - 1) / BKE;
+    const int fr = lane & 15, fq = lane >> 4;
+    load_step();
+    for (int t = 0; t < nk; ++t) {
+        uint4* buf = lds[t & 1];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) buf[(row0 + 64 * i) * 4 + slot] = ra[i];
+#pragma unroll
+        for (int j = 0; j < BCH; ++j) buf[(BM + row0 + 64 * j) * 4 + slot] = rb[j];
+        __syncthreads();
+        if (t + 1 < nk) load_step();
+        uint4 af[4], bf[NI];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int r = wm * 64 + i * 16 + fr;
+            af[i] = buf[r * 4 + (fq ^ swz4(r))];
+        }
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            int r = wn * (BN / 2) + j * 16 + fr;
+            bf[j] = buf[(BM + r) * 4 + (fq ^ swz4(r))];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j) mfma_step<T>(af[i], bf[j], acc[i][j]);
+    }
+
+    // ---- epilogue: bias + residual, direct stores ---------------------------------------
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+        const int n = bn * BN + wn * (BN / 2) + j * 16 + fr;
+        if (n >= N) continue;
+        const float bv = bias ? bias[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = bm * BM + wm * 64 + i * 16 + fq * 4 + r;
+                if (m >= M) continue;
+                float v = acc[i][j][r] + bv;
+                if (residual) v += ldf<T>(residual + (long)m * g.res_ld + n);
+                if (out_f32) ((float*)out)[(long)m * g.out_ld + n] = v;
+                else stf<T>((T*)out + (long)m * g.out_ld + n, v);
+            }
+        }
+    }
+}
+
+static int check_geom_mfma(const char* who, const NvaeConvGeom* g) {
+    NVAE_REQUIRE(g, "%s: NULL geometry", who);
+    NVAE_REQUIRE(g->B > 0 && g->Hin > 0 && g->Win > 0 && g->Cin > 0 && g->Hout > 0 && g->Wout > 0 && g->Cout > 0,
+                 "%s: non-positive dimension", who);
+    NVAE_REQUIRE(g->KH > 0 && g->KW > 0 && g->KH <= 7 && g->KW <= 7 && g->stride >= 1 && g->div >= 1,
+                 "%s: bad kernel/stride/div", who);
+    NVAE_REQUIRE(g->in_ld >= g->Cin && g->out_ld >= g->Cout, "%s: leading dimensions too small", who);
+    NVAE_REQUIRE((long)g->B * g->Hout * g->Wout < (1L << 23) && (long)g->B * g->Hin * g->Win < (1L << 23),
+                 "%s: more than 2^23 pixels per call unsupported", who);
+    return NVAE_OK;
+}
+
+template <typename T>
+static int launch_conv_gemm(const NvaeConvGeom* g, const void* src, const void* wT, int w_ld,
+                            const float* bias, const void* residual, void* out, int out_f32,
+                            hipStream_t s) {
+    const int M = g->B * g->Hout * g->Wout, K = g->KH * g->KW * g->Cin, N = g->Cout;
+    FastDiv fd_hw = make_fastdiv((unsigned)(g->Hout * g->Wout)), fd_w = make_fastdiv((unsigned)g->Wout);
+    const int mt = cdiv(M, 128);
+#define LAUNCH_BN(BN_)                                                                              \
+    {                                                                                               \
+        int nt = cdiv(N, BN_);                                                                      \
+        hipLaunchKernelGGL((k_conv_gemm<T, BN_>), mt * nt, 256, 0, s, *g, (const T*)src, (const T*)wT, \
+                           w_ld, bias, (const T*)residual, out, out_f32, M, K, nt, mt * nt, fd_hw, fd_w); \
+    }
+    // pick the N tile with the least padding waste; prefer the larger on ties
+    int best = 64;
+    long waste_best = (long)cdiv(N, 64) * 64;
+    const int cands[2] = {128, 192};
+    for (int c = 0; c < 2; ++c) {
+        long w = (long)cdiv(N, cands[c]) * cands[c];
+        if (w <= waste_best) { waste_best = w; best = cands[c]; }
+    }
+    if (best == 192) LAUNCH_BN(192)
+    else if (best == 128) LAUNCH_BN(128)
+    else LAUNCH_BN(64)
+#undef LAUNCH_BN
+    return 0;
+}
+
+extern "C" int nvae_conv_gemm(int dtype, const NvaeConvGeom* g, const void* src, const void* wT, int w_ld,
+                              const float* bias, const void* residual, void* out, int out_f32,
+                              void* stream) {
+    if (int e = check_geom_mfma("conv_gemm", g)) return e;
+    NVAE_REQUIRE(src && wT && out, "conv_gemm: NULL pointer");
+    const int ve = (dtype == NVAE_BF16) ? 8 : 4;
+    NVAE_REQUIRE(g->Cin % ve == 0 && g->in_ld % ve == 0 && w_ld % ve == 0,
+                 "conv_gemm: Cin=%d in_ld=%d w_ld=%d must be multiples of %d (use nvae_conv_direct)", g->Cin, g->in_ld, w_ld, ve);
+    NVAE_REQUIRE(w_ld >= g->KH * g->KW * g->Cin, "conv_gemm: w_ld too small");
+    NVAE_REQUIRE(aligned16(src) && aligned16(wT), "conv_gemm: src/wT must be 16-B aligned");
+    NVAE_REQUIRE(!residual || g->res_ld >= g->Cout, "conv_gemm: res_ld too small");
+    DISPATCH_T(dtype, launch_conv_gemm<T>(g, src, wT, w_ld, bias, residual, out, out_f32, (hipStream_t)stream);)
+    NVAE_LAUNCH_CHECK("conv_gemm");
+    return NVAE_OK;
+}
+
+// =========================================================================================
+// weight gradient
+// =========================================================================================
+// LDS image: [RS pixels][COLS channels]; byte offset of 16-B chunk `cc` of pixel row `m`.
+template <typename T, int COLS>
+__device__ __forceinline__ int img_off(int m, int cc) {
+    if constexpr (sizeof(T) == 2) {
+        // 32-B segments (16 bf16) XOR-swizzled so the 8 rows a half-wave transposes hit 8 bank octets
+        constexpr int ROWB = COLS * 2;
+        int seg = cc >> 1;
+        int s = (COLS >= 128) ? ((m & 3) | (((m >> 3) & 1) << 2)) : (((m >> 1) & 1) | (((m >> 3) & 1) << 1));
+        return m * ROWB + ((seg ^ s) << 5) + ((cc & 1) << 4);
+    } else {
+        constexpr int ROWB = COLS * 4;
+        int seg = cc >> 2;   // 64-B segments (16 floats)
+        return m * ROWB + ((seg ^ (m & 1)) << 6) + ((cc & 3) << 4);
+    }
+}
+
+template <typename T, int BNT>
+__global__ __launch_bounds__(256, 2) void k_conv_wgrad(NvaeConvGeom g, const T* __restrict__ x,
+                                                       const T* __restrict__ dy, float* dw, int dw_ld,
+                                                       int M, int K, int n_tiles, int m_per_split,
+                                                       FastDiv fd_hw, FastDiv fd_w) {
+    constexpr int BKT = 128;
+    constexpr int VE = Tr<T>::VE;
+    constexpr int RS = 4 * VE;                 // pixels per reduction step (32 bf16 / 16 f32)
+    constexpr int CPR_A = BKT / VE;            // chunks per A-image row
+    constexpr int CPR_B = BNT / VE;
+    constexpr int A_CH = RS * CPR_A / 256;     // = 2
+    constexpr int B_CH = RS * CPR_B / 256;     // 128 -> 2, 64 -> 1
+    constexpr int NI = BNT / 32;
+    constexpr int A_BYTES = RS * BKT * (int)sizeof(T);
+    constexpr int B_BYTES = RS * BNT * (int)sizeof(T);
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2][A_BYTES + B_BYTES];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wk = wave >> 1, wn = wave & 1;
+    const int kt = blockIdx.x / n_tiles, nt = blockIdx.x - kt * n_tiles;
+    const int k0 = kt * BKT, n0 = nt * BNT;
+    const int N = g.Cout;
+    const int m_begin = blockIdx.y * m_per_split;
+    int m_end = m_begin + m_per_split;
+    if (m_end > M) m_end = M;
+
+    // A-side: fixed k chunk per thread
+    const int a_cc = tid % CPR_A, a_row0 = tid / CPR_A;
+    const int kcol = k0 + a_cc * VE;
+    const bool kval = kcol < K;
+    int tap = kval ? kcol / g.Cin : 0;
+    const int ci = kval ? kcol - tap * g.Cin : 0;
+    const int kh = tap / g.KW, kw = tap - kh * g.KW;
+    const int hlim = g.Hin * g.div, wlim = g.Win * g.div;
+    // B-side
+    const int b_cc = tid % CPR_B, b_row0 = tid / CPR_B;
+    const int ncol = n0 + b_cc * VE;
+    const bool nval = ncol < N;
+
+    uint4 ra[A_CH], rb[B_CH];
+    auto load_step = [&](int mbase) {
+#pragma unroll
+        for (int i = 0; i < A_CH; ++i) {
+            int m = mbase + a_row0 + i * (256 / CPR_A);
+            ra[i] = make_uint4(0, 0, 0, 0);
+            if (kval && m < m_end) {
+                unsigned b = fdiv((unsigned)m, fd_hw);
+                unsigned rem = (unsigned)m - b * fd_hw.d;
+                unsigned ho = fdiv(rem, fd_w);
+                unsigned wo = rem - ho * fd_w.d;
+                int hc = (int)ho * g.stride - g.pad_t + kh, wc = (int)wo * g.stride - g.pad_l + kw;
+                bool ok = hc >= 0 && hc < hlim && wc >= 0 && wc < wlim;
+                int hs = hc, ws = wc;
+                if (g.div != 1) {
+                    hs = hc / g.div; ws = wc / g.div;
+                    if (g.exact) ok = ok && (hs * g.div == hc) && (ws * g.div == wc);
+                }
+                if (ok) ra[i] = *(const uint4*)(x + ((long)b * g.Hin * g.Win + (long)hs * g.Win + ws) * g.in_ld + ci);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < B_CH; ++i) {
+            int m = mbase + b_row0 + i * (256 / CPR_B);
+            rb[i] = make_uint4(0, 0, 0, 0);
+            if (nval && m < m_end) rb[i] = *(const uint4*)(dy + (long)m * g.out_ld + ncol);
+        }
+    };
+
+    f32x4 acc[4][NI];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int fr = lane & 15, fq = lane >> 4;
+    const int nsteps = (m_end - m_begin + RS - 1) / RS;
+    if (nsteps > 0) load_step(m_begin);
+    for (int t = 0; t < nsteps; ++t) {
+        unsigned char* bufA = lds[t & 1];
+        unsigned char* bufB = bufA + A_BYTES;
+#pragma unroll
+        for (int i = 0; i < A_CH; ++i)
+            *(uint4*)(bufA + img_off<T, BKT>(a_row0 + i * (256 / CPR_A), a_cc)) = ra[i];
+#pragma unroll
+        for (int i = 0; i < B_CH; ++i)
+            *(uint4*)(bufB + img_off<T, BNT>(b_row0 + i * (256 / CPR_B), b_cc)) = rb[i];
+        __syncthreads();
+        if (t + 1 < nsteps) load_step(m_begin + (t + 1) * RS);
+
+        if constexpr (sizeof(T) == 2) {
+            // operand (lane: k-row/col fr, pixels 8*fq .. 8*fq+7) = two transposed 4x16 reads
+            const int q = fr >> 2, p = fr & 3;
+            const int mr = 8 * fq + q;
+            bf16x8 af[4], bfr[NI];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int seg = wk * 4 + i;
+                int s0 = (mr & 3) | (((mr >> 3) & 1) << 2);
+                int mr1 = mr + 4;
+                int s1 = (mr1 & 3) | (((mr1 >> 3) & 1) << 2);
+                auto lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                    (__attribute__((address_space(3))) bf16x4*)(bufA + mr * (BKT * 2) + ((seg ^ s0) << 5) + p * 8));
+                auto hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                    (__attribute__((address_space(3))) bf16x4*)(bufA + mr1 * (BKT * 2) + ((seg ^ s1) << 5) + p * 8));
+                af[i] = (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            }
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+                const int seg = wn * (BNT / 32) + j;
+                int mr1 = mr + 4;
+                int s0, s1;
+                if (BNT >= 128) {
+                    s0 = (mr & 3) | (((mr >> 3) & 1) << 2);
+                    s1 = (mr1 & 3) | (((mr1 >> 3) & 1) << 2);
+                } else {
+                    s0 = ((mr >> 1) & 1) | (((mr >> 3) & 1) << 1);
+                    s1 = ((mr1 >> 1) & 1) | (((mr1 >> 3) & 1) << 1);
+                }
+                auto lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                    (__attribute__((address_space(3))) bf16x4*)(bufB + mr * (BNT * 2) + ((seg ^ s0) << 5) + p * 8));
+                auto hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                    (__attribute__((address_space(3))) bf16x4*)(bufB + mr1 * (BNT * 2) + ((seg ^ s1) << 5) + p * 8));
+                bfr[j] = (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        } else {
+            // f32: 16x16x4, lane (fr, fq) supplies A[k-row fr][pixel 4*s + fq], B[pixel 4*s + fq][n fr]
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int m = 4 * s + fq;
+                float af[4], bfr[NI];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    int col = wk * 64 + i * 16 + fr;
+                    af[i] = *(const float*)(bufA + m * (BKT * 4) + (((col >> 4) ^ (m & 1)) << 6) + ((col & 15) << 2));
+                }
+#pragma unroll
+                for (int j = 0; j < NI; ++j) {
+                    int col = wn * (BNT / 2) + j * 16 + fr;
+                    bfr[j] = *(const float*)(bufB + m * (BNT * 4) + (((col >> 4) ^ (m & 1)) << 6) + ((col & 15) << 2));
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < NI; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bfr[j], acc[i][j], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- epilogue: f32 atomics into the flat gradient buffer ------------------------------
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+        const int n = n0 + wn * (BNT / 2) + j * 16 + fr;
+        if (n >= N) continue;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int k = k0 + wk * 64 + i * 16 + fq * 4 + r;
+                if (k < K) atomicAdd(dw + (long)k * dw_ld + n, acc[i][j][r]);
+            }
+    }
+}
+
+template <typename T>
+static int launch_conv_wgrad(const NvaeConvGeom* g, const void* x, const void* dy, float* dw, int dw_ld,
+                             hipStream_t s) {
+    constexpr int RS = 4 * Tr<T>::VE;
+    const int M = g->B * g->Hout * g->Wout, K = g->KH * g->KW * g->Cin, N = g->Cout;
+    FastDiv fd_hw = make_fastdiv((unsigned)(g->Hout * g->Wout)), fd_w = make_fastdiv((unsigned)g->Wout);
+    const int kt = cdiv(K, 128);
+    const bool wide = ((long)cdiv(N, 128) * 128 <= (long)cdiv(N, 64) * 64);
+    const int nt = wide ? cdiv(N, 128) : cdiv(N, 64);
+    const int tiles = kt * nt;
+    // split the pixel reduction so that the grid holds ~1024 workgroups, >= 8 steps per split
+    int nsplit = 1024 / tiles;
+    int max_split = M / (RS * 8);
+    if (nsplit > max_split) nsplit = max_split;
+    if (nsplit < 1) nsplit = 1;
+    int mps = cdiv(M, nsplit);
+    mps = ((mps + RS - 1) / RS) * RS;
+    nsplit = cdiv(M, mps);
+    dim3 grid(tiles, nsplit);
+    if (wide)
+        hipLaunchKernelGGL((k_conv_wgrad<T, 128>), grid, 256, 0, s, *g, (const T*)x, (const T*)dy, dw, dw_ld, M, K, nt, mps, fd_hw, fd_w);
+    else
+        hipLaunchKernelGGL((k_conv_wgrad<T, 64>), grid, 256, 0, s, *g, (const T*)x, (const T*)dy, dw, dw_ld, M, K, nt, mps, fd_hw, fd_w);
+    return 0;
+}
+
+extern "C" int nvae_conv_wgrad(int dtype, const NvaeConvGeom* g, const void* x, const void* dy, float* dw,
+                               int dw_ld, void* stream) {
+    if (int e = check_geom_mfma("conv_wgrad", g)) return e;
+    NVAE_REQUIRE(x && dy && dw && dw_ld >= g->Cout, "conv_wgrad: bad args");
+    const int ve = (dtype == NVAE_BF16) ? 8 : 4;
+    NVAE_REQUIRE(g->Cin % ve == 0 && g->in_ld % ve == 0 && g->Cout % ve == 0 && g->out_ld % ve == 0,
+                 "conv_wgrad: Cin=%d Cout=%d and their lds must be multiples of %d (use nvae_conv_direct_wgrad)", g->Cin, g->Cout, ve);
+    NVAE_REQUIRE(aligned16(x) && aligned16(dy), "conv_wgrad: x/dy must be 16-B aligned");
+    DISPATCH_T(dtype, launch_conv_wgrad<T>(g, x, dy, dw, dw_ld, (hipStream_t)stream);)
+    NVAE_LAUNCH_CHECK("conv_wgrad");
+    return NVAE_OK;
+}

@@ -1,0 +1,239 @@
+// Elementwise kernels: activations, add, cast, nearest-upsample backward, Philox randn, Adamax.
+// All are HBM-bound streaming kernels: 16-B (bf16) / 32-B (f32) per lane per iteration,
+// grid capped at 2048 blocks with a grid-stride loop.
+#include "common.h"
+
+thread_local char g_nvae_err[512] = {0};
+extern "C" const char* nvae_last_error(void) { return g_nvae_err; }
+extern "C" int nvae_abi_version(void) { return 1; }
+
+static inline int ew_grid(long n8) {
+    long g = (n8 + 255) / 256;
+    return (int)(g < 1 ? 1 : (g > 2048 ? 2048 : g));
+}
+
+template <typename T, int OP>
+__global__ void k_unary_fwd(const T* __restrict__ x, T* __restrict__ y, long n8, float a, float b) {
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n8; i += gridDim.x * 256L) {
+        float v[8];
+        V8<T>::ld(x + i * 8, v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if (OP == NVAE_OP_AFFINE) v[j] = a * v[j] + b;
+            else if (OP == NVAE_OP_SWISH) v[j] = swishf_(v[j]);
+            else v[j] = eluf_(v[j]);
+        }
+        V8<T>::st(y + i * 8, v);
+    }
+}
+
+template <typename T, int OP>
+__global__ void k_unary_bwd(const T* __restrict__ x, const T* __restrict__ dy, T* dx, long n8, int acc) {
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n8; i += gridDim.x * 256L) {
+        float v[8], g[8], o[8];
+        V8<T>::ld(x + i * 8, v);
+        V8<T>::ld(dy + i * 8, g);
+        if (acc) V8<T>::ld(dx + i * 8, o);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float d = (OP == NVAE_OP_SWISH) ? dswishf_(v[j]) : deluf_(v[j]);
+            o[j] = (acc ? o[j] : 0.f) + g[j] * d;
+        }
+        V8<T>::st(dx + i * 8, o);
+    }
+}
+
+template <typename T>
+__global__ void k_add(T* dst, const T* __restrict__ src, long n8, int acc) {
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n8; i += gridDim.x * 256L) {
+        float s[8], d[8];
+        V8<T>::ld(src + i * 8, s);
+        if (acc) {
+            V8<T>::ld(dst + i * 8, d);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s[j] += d[j];
+        }
+        V8<T>::st(dst + i * 8, s);
+    }
+}
+
+template <typename TS, typename TD>
+__global__ void k_cast(const TS* __restrict__ src, TD* __restrict__ dst, long n8) {
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n8; i += gridDim.x * 256L) {
+        float v[8];
+        V8<TS>::ld(src + i * 8, v);
+        V8<TD>::st(dst + i * 8, v);
+    }
+}
+
+// dx[b,h,w,c] (+)= sum_{i,j<f} dxu[b, h*f+i, w*f+j, c]
+template <typename T>
+__global__ void k_upsample_pool(const T* __restrict__ dxu, T* dx, int H, int W, int C8, int f, long n8,
+                                int acc) {
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n8; i += gridDim.x * 256L) {
+        int c8 = (int)(i % C8);
+        long p = i / C8;
+        int w = (int)(p % W);
+        long q = p / W;
+        int h = (int)(q % H);
+        long b = q / H;
+        float o[8];
+        if (acc) V8<T>::ld(dx + i * 8, o);
+        else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = 0.f;
+        }
+        for (int ii = 0; ii < f; ++ii)
+            for (int jj = 0; jj < f; ++jj) {
+                long src = ((b * (H * f) + (h * f + ii)) * (long)(W * f) + (w * f + jj)) * C8 + c8;
+                float v[8];
+                V8<T>::ld(dxu + src * 8, v);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] += v[j];
+            }
+        V8<T>::st(dx + i * 8, o);
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// Philox4x32-10 + Box-Muller.  Each thread produces 4 normals from counter (ctr_base + tid).
+// The 64-bit base counter lives in device memory and is advanced by a trailing 1-thread kernel
+// so that graph replays draw fresh noise.
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ void philox_round(unsigned (&c)[4], unsigned k0, unsigned k1) {
+    const unsigned M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
+    unsigned hi0 = __umulhi(M0, c[0]), lo0 = M0 * c[0];
+    unsigned hi1 = __umulhi(M1, c[2]), lo1 = M1 * c[2];
+    unsigned n0 = hi1 ^ c[1] ^ k0, n1 = lo1, n2 = hi0 ^ c[3] ^ k1, n3 = lo0;
+    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+}
+
+__global__ void k_randn(float* __restrict__ out, long n, unsigned long long seed,
+                        const unsigned long long* __restrict__ counter) {
+    unsigned long long base = *counter;
+    long n4 = (n + 3) / 4;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n4; i += gridDim.x * 256L) {
+        unsigned long long ctr = base + (unsigned long long)i;
+        unsigned c[4] = {(unsigned)ctr, (unsigned)(ctr >> 32), 0x5eedu, 0u};
+        unsigned k0 = (unsigned)seed, k1 = (unsigned)(seed >> 32);
+#pragma unroll
+        for (int r = 0; r < 10; ++r) {
+            philox_round(c, k0, k1);
+            k0 += 0x9E3779B9u;
+            k1 += 0xBB67AE85u;
+        }
+        float u[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) u[j] = ((float)(c[j] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+        float r0 = sqrtf(-2.f * __logf(u[0])), r1 = sqrtf(-2.f * __logf(u[2]));
+        float s0, c0, s1, c1;
+        __sincosf(6.283185307179586f * u[1], &s0, &c0);
+        __sincosf(6.283185307179586f * u[3], &s1, &c1);
+        float z[4] = {r0 * c0, r0 * s0, r1 * c1, r1 * s1};
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (i * 4 + j < n) out[i * 4 + j] = z[j];
+    }
+}
+__global__ void k_advance_counter(unsigned long long* counter, unsigned long long by) { *counter += by; }
+
+// Adamax, Keras formulation: m = b1 m + (1-b1) g; u = max(b2 u, |g|); p -= lr_t * m / (u + eps)
+__global__ void k_adamax(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                         float* __restrict__ u, long n4, const float* __restrict__ hyper, float b1,
+                         float b2, float eps) {
+    const float lr_t = hyper[NVAE_HY_LR];
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n4; i += gridDim.x * 256L) {
+        float4 pv = ((float4*)p)[i], gv = ((const float4*)g)[i], mv = ((float4*)m)[i], uv = ((float4*)u)[i];
+        float* pp = (float*)&pv; float* gp = (float*)&gv; float* mp = (float*)&mv; float* up = (float*)&uv;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            mp[j] = b1 * mp[j] + (1.f - b1) * gp[j];
+            up[j] = fmaxf(b2 * up[j], fabsf(gp[j]));
+            pp[j] -= lr_t * mp[j] / (up[j] + eps);
+        }
+        ((float4*)p)[i] = pv; ((float4*)m)[i] = mv; ((float4*)u)[i] = uv;
+    }
+}
+
+
+extern "C" int nvae_unary_fwd(int dtype, int op, const void* x, void* y, long n, float a, float b,
+                              void* stream) {
+    NVAE_REQUIRE(n > 0 && n % 8 == 0, "unary_fwd: n=%ld must be a positive multiple of 8", n);
+    NVAE_REQUIRE(aligned16(x) && aligned16(y), "unary_fwd: pointers must be 16-B aligned");
+    NVAE_REQUIRE(op >= 0 && op <= 2, "unary_fwd: bad op %d", op);
+    long n8 = n / 8;
+    hipStream_t s = (hipStream_t)stream;
+    DISPATCH_T(dtype,
+        if (op == NVAE_OP_AFFINE) hipLaunchKernelGGL((k_unary_fwd<T, 0>), ew_grid(n8), 256, 0, s, (const T*)x, (T*)y, n8, a, b);
+        else if (op == NVAE_OP_SWISH) hipLaunchKernelGGL((k_unary_fwd<T, 1>), ew_grid(n8), 256, 0, s, (const T*)x, (T*)y, n8, a, b);
+        else hipLaunchKernelGGL((k_unary_fwd<T, 2>), ew_grid(n8), 256, 0, s, (const T*)x, (T*)y, n8, a, b);)
+    NVAE_LAUNCH_CHECK("unary_fwd");
+    return NVAE_OK;
+}
+
+extern "C" int nvae_unary_bwd(int dtype, int op, const void* x, const void* dy, void* dx, long n,
+                              int accumulate, void* stream) {
+    NVAE_REQUIRE(n > 0 && n % 8 == 0, "unary_bwd: n=%ld must be a positive multiple of 8", n);
+    NVAE_REQUIRE(aligned16(x) && aligned16(dy) && aligned16(dx), "unary_bwd: alignment");
+    NVAE_REQUIRE(op == NVAE_OP_SWISH || op == NVAE_OP_ELU, "unary_bwd: bad op %d", op);
+    long n8 = n / 8;
+    hipStream_t s = (hipStream_t)stream;
+    DISPATCH_T(dtype,
+        if (op == NVAE_OP_SWISH) hipLaunchKernelGGL((k_unary_bwd<T, 1>), ew_grid(n8), 256, 0, s, (const T*)x, (const T*)dy, (T*)dx, n8, accumulate);
+        else hipLaunchKernelGGL((k_unary_bwd<T, 2>), ew_grid(n8), 256, 0, s, (const T*)x, (const T*)dy, (T*)dx, n8, accumulate);)
+    NVAE_LAUNCH_CHECK("unary_bwd");
+    return NVAE_OK;
+}
+
+extern "C" int nvae_add(int dtype, void* dst, const void* src, long n, int accumulate, void* stream) {
+    NVAE_REQUIRE(n > 0 && n % 8 == 0, "add: n=%ld must be a positive multiple of 8", n);
+    NVAE_REQUIRE(aligned16(dst) && aligned16(src), "add: alignment");
+    long n8 = n / 8;
+    DISPATCH_T(dtype, hipLaunchKernelGGL((k_add<T>), ew_grid(n8), 256, 0, (hipStream_t)stream, (T*)dst, (const T*)src, n8, accumulate);)
+    NVAE_LAUNCH_CHECK("add");
+    return NVAE_OK;
+}
+
+extern "C" int nvae_cast(int sd, int dd, const void* src, void* dst, long n, void* stream) {
+    NVAE_REQUIRE(n > 0 && n % 8 == 0, "cast: n=%ld must be a positive multiple of 8", n);
+    NVAE_REQUIRE(aligned16(dst) && aligned16(src), "cast: alignment");
+    long n8 = n / 8;
+    hipStream_t s = (hipStream_t)stream;
+    if (sd == NVAE_F32 && dd == NVAE_BF16) hipLaunchKernelGGL((k_cast<float, bf16>), ew_grid(n8), 256, 0, s, (const float*)src, (bf16*)dst, n8);
+    else if (sd == NVAE_BF16 && dd == NVAE_F32) hipLaunchKernelGGL((k_cast<bf16, float>), ew_grid(n8), 256, 0, s, (const bf16*)src, (float*)dst, n8);
+    else if (sd == NVAE_F32 && dd == NVAE_F32) hipLaunchKernelGGL((k_cast<float, float>), ew_grid(n8), 256, 0, s, (const float*)src, (float*)dst, n8);
+    else if (sd == NVAE_BF16 && dd == NVAE_BF16) hipLaunchKernelGGL((k_cast<bf16, bf16>), ew_grid(n8), 256, 0, s, (const bf16*)src, (bf16*)dst, n8);
+    else NVAE_FAIL(NVAE_EINVAL, "cast: bad dtypes %d->%d", sd, dd);
+    NVAE_LAUNCH_CHECK("cast");
+    return NVAE_OK;
+}
+
+extern "C" int nvae_upsample_pool_bwd(int dtype, const void* dxu, void* dx, int B, int H, int W, int C,
+                                      int f, int accumulate, void* stream) {
+    NVAE_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0 && f >= 1, "upsample_pool_bwd: bad shape");
+    NVAE_REQUIRE(aligned16(dxu) && aligned16(dx), "upsample_pool_bwd: alignment");
+    long n8 = (long)B * H * W * (C / 8);
+    DISPATCH_T(dtype, hipLaunchKernelGGL((k_upsample_pool<T>), ew_grid(n8), 256, 0, (hipStream_t)stream, (const T*)dxu, (T*)dx, H, W, C / 8, f, n8, accumulate);)
+    NVAE_LAUNCH_CHECK("upsample_pool_bwd");
+    return NVAE_OK;
+}
+
+extern "C" int nvae_randn(float* out, long n, unsigned long long seed, unsigned long long* counter_dev,
+                          void* stream) {
+    NVAE_REQUIRE(n > 0 && out && counter_dev, "randn: bad args");
+    long n4 = (n + 3) / 4;
+    hipLaunchKernelGGL(k_randn, ew_grid(n4), 256, 0, (hipStream_t)stream, out, n, seed, counter_dev);
+    hipLaunchKernelGGL(k_advance_counter, 1, 1, 0, (hipStream_t)stream, counter_dev, (unsigned long long)n4);
+    NVAE_LAUNCH_CHECK("randn");
+    return NVAE_OK;
+}
+
+extern "C" int nvae_adamax(float* p, const float* g, float* m, float* u, long n, const float* hyper,
+                           float beta1, float beta2, float eps, void* stream) {
+    NVAE_REQUIRE(n > 0 && n % 4 == 0, "adamax: n=%ld must be a positive multiple of 4", n);
+    NVAE_REQUIRE(aligned16(p) && aligned16(g) && aligned16(m) && aligned16(u), "adamax: alignment");
+    long n4 = n / 4;
+    hipLaunchKernelGGL(k_adamax, ew_grid(n4), 256, 0, (hipStream_t)stream, p, g, m, u, n4, hyper, beta1, beta2, eps);
+    NVAE_LAUNCH_CHECK("adamax");
+    return NVAE_OK;
+}

@@ -1,0 +1,384 @@
+"""NVAE model, mirroring the reference's models.py (constructor arguments, call / train_step /
+sample / sample_with_z / calculate_* methods), executed by libnvae_hip.so on one MI355X per process.
+
+Semantics (SURVEY "Quirks"): `training` is explicit (Q1): train_step runs batch-statistics BN and
+one spectral-norm power iteration per conv; call/sample run moving-statistics BN and no SN.  The
+`steps` resume bug (Q14) is fixed by the caller (train.py)."""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+
+from . import _lib as L
+from . import ops
+from .common import DistributionParams
+from .decoder import Decoder, DecoderSampleCombiner
+from .encoder import Encoder
+from .ops import Ctx, Var
+from .params import ParamStore
+from .postprocess import Postprocess
+from .preprocess import Preprocess
+
+ADAMAX_B1, ADAMAX_B2, ADAMAX_EPS = 0.9, 0.999, 1e-7   # Keras Adamax defaults [3P], train.py:131
+
+
+class NVAE:
+    def __init__(self, n_encoder_channels, n_decoder_channels, res_cells_per_group, n_preprocess_blocks,
+                 n_preprocess_cells, n_latent_per_group, n_latent_scales, n_groups_per_scale,
+                 n_postprocess_blocks, n_post_process_cells, sr_lambda, scale_factor, total_epochs,
+                 n_total_iterations, step_based_warmup, input_shape, *, device="cuda:0",
+                 dtype=torch.bfloat16, seed=1, lr_decay_steps: Optional[int] = None, base_lr=1e-3):
+        """Positional arguments as models.py:17-36.  input_shape = [B, H, W, C] (B ignored)."""
+        assert len(n_groups_per_scale) == n_latent_scales
+        self.sr_lambda = sr_lambda
+        self.n_latent_per_group = n_latent_per_group
+        self.n_latent_scales = n_latent_scales
+        self.n_groups_per_scale = [int(g) for g in n_groups_per_scale]
+        self.n_total_iterations = n_total_iterations
+        self.n_preprocess_blocks = n_preprocess_blocks
+        self.total_epochs = total_epochs
+        self.step_based_warmup = step_based_warmup
+        self.scale_factor = scale_factor
+        self.device = torch.device(device)
+        self.dtype = dtype
+        self.seed = seed
+        self.lr_decay_steps = lr_decay_steps or n_total_iterations
+        self.base_lr = base_lr
+        input_shape = [int(v) for v in input_shape]
+        self.input_shape = input_shape
+        L.load()   # fail loudly now if the HIP library is missing
+
+        ps = ParamStore(seed)
+        self.ps = ps
+        self.preprocess = Preprocess(ps, n_encoder_channels, n_preprocess_blocks, n_preprocess_cells,
+                                     scale_factor, input_shape)
+        mult = self.preprocess.mult
+        self.encoder = Encoder(ps, n_encoder_channels, n_decoder_channels, n_latent_per_group,
+                               res_cells_per_group, n_latent_scales, self.n_groups_per_scale, mult,
+                               scale_factor, self.preprocess.output_shape_)
+        mult = self.encoder.mult
+        self.decoder = Decoder(ps, n_encoder_channels, n_decoder_channels, n_latent_per_group,
+                               res_cells_per_group, n_latent_scales,
+                               list(reversed(self.n_groups_per_scale)), mult, scale_factor,
+                               self.encoder.output_shape_)
+        mult = self.decoder.mult
+        self.postprocess = Postprocess(ps, n_postprocess_blocks, n_post_process_cells, mult,
+                                       n_decoder_channels, scale_factor, out_channels=input_shape[3])
+        self.n_groups = self.decoder.n_groups
+        # per-image activation footprint decides the scratch pool; generous fixed size
+        ps.finalize(self.device, dtype, zero_pool_floats=1 << 24)
+
+        self.epoch = 0          # updated at the start of each epoch (models.py:82-83)
+        self.steps = 0          # updated for each training step (models.py:86-87)
+        self.opt_iterations = 0
+        self.reducer = None     # parallel.GradReducer when data-parallel
+        dev = self.device
+        self.hyper = torch.zeros(L.HY_SIZE, dtype=torch.float32, device=dev)
+        self.results = torch.zeros(L.RES_SIZE, dtype=torch.float32, device=dev)
+        self.alphas = self.calculate_kl_alphas(n_latent_scales, self.n_groups_per_scale).to(dev)
+        self.coeff = torch.ones(self.n_groups, dtype=torch.float32, device=dev)
+        self.am = torch.zeros(self.n_groups, dtype=torch.float32, device=dev)
+        self.rng_counter = torch.zeros(1, dtype=torch.int64, device=dev)
+        self._buf: Dict[int, Dict[str, torch.Tensor]] = {}
+        self._plan = None
+
+    # ------------------------------------------------------------------ helpers
+    def n_trainable(self) -> int:
+        return self.ps.n_trainable
+
+    def eps_shapes(self, B: int):
+        shapes, hw = [], self.decoder.z0_shape[0]
+        for g in reversed(self.n_groups_per_scale):
+            shapes += [(B, hw, hw, self.n_latent_per_group)] * g
+            hw *= self.scale_factor
+        return shapes
+
+    def _buffers(self, B: int) -> Dict[str, torch.Tensor]:
+        if B not in self._buf:
+            dev = self.device
+            self._buf[B] = {
+                "kl_all": torch.zeros(self.n_groups, B, dtype=torch.float32, device=dev),
+                "kl_loss": torch.zeros(B, dtype=torch.float32, device=dev),
+                "recon": torch.zeros(B, dtype=torch.float32, device=dev),
+                "log_p": torch.zeros(B, dtype=torch.float32, device=dev),
+                "log_q": torch.zeros(B, dtype=torch.float32, device=dev),
+            }
+        return self._buf[B]
+
+    def _as_input(self, data) -> torch.Tensor:
+        if isinstance(data, (tuple, list)):
+            data = data[0]   # labelled data: drop the label (models.py:113-115)
+        x = data.to(self.device)
+        if x.dtype != self.dtype:
+            x = x.to(self.dtype)
+        return x.contiguous()
+
+    def _draw_eps(self, ctx: Ctx, B: int, eps_list):
+        if eps_list is not None:
+            return [e.to(self.device, torch.float32).contiguous() for e in eps_list]
+        return [ops.randn(ctx, s, self.seed, self.rng_counter) for s in self.eps_shapes(B)]
+
+    # ------------------------------------------------------------------ forward
+    def _forward(self, ctx: Ctx, x: torch.Tensor, eps_list, nll=False, mu_sigma_list=None) -> Var:
+        B = x.shape[0]
+        buf = self._buffers(B)
+        eps = self._draw_eps(ctx, B, eps_list)
+        h = self.preprocess(ctx, x)
+        enc_dec_combiners, final_x = self.encoder(ctx, h)
+        enc_dec_combiners.reverse()    # bottom-up -> top-down, models.py:93
+        if nll:
+            buf["log_p"].zero_(); buf["log_q"].zero_()
+        s = self.decoder(ctx, final_x, enc_dec_combiners, eps, buf["kl_all"], self.coeff, self.hyper,
+                         1.0 / B, nll=nll, log_p=buf["log_p"], log_q=buf["log_q"],
+                         mu_sigma_list=mu_sigma_list)
+        return self.postprocess(ctx, s)
+
+    def __call__(self, inputs, nll=False, eps_list=None, training=False):
+        """NVAE.call, models.py:89-98 -> (reconstruction logits, z_params, log_p, log_q)."""
+        x = self._as_input(inputs)
+        B = x.shape[0]
+        self.ps.begin_step()
+        self.ps.prepare_weights(spectral_norm=False)
+        ctx = Ctx(self.ps, self.dtype, training=training, record=False)
+        ms = [torch.empty((4,) + s, dtype=torch.float32, device=self.device) for s in self.eps_shapes(B)]
+        logits = self._forward(ctx, x, eps_list, nll=nll, mu_sigma_list=ms)
+        buf = self._buffers(B)
+        z_params = [DistributionParams(m[0], m[1], m[2], m[3]) for m in ms]
+        if nll:
+            return logits.t, z_params, buf["log_p"].clone(), buf["log_q"].clone()
+        zeros = torch.zeros(B, dtype=torch.float32, device=self.device)
+        return logits.t, z_params, zeros, zeros.clone()
+
+    # ------------------------------------------------------------------ losses (models.py:191-267)
+    @staticmethod
+    def calculate_kl_alphas(num_scales, groups_per_scale) -> torch.Tensor:
+        """models.py:227-237."""
+        coeffs = []
+        for i in range(num_scales):
+            g = groups_per_scale[num_scales - i - 1]
+            coeffs.append(np.square(2 ** i) / g * np.ones(g, dtype=np.float32))
+        c = np.concatenate(coeffs)
+        return torch.from_numpy((c / c.min()).astype(np.float32))
+
+    def beta(self) -> float:
+        """models.py:121-122."""
+        m = self.steps if self.step_based_warmup else self.epoch
+        return min(m / (0.3 * self.n_total_iterations), 1)
+
+    def learning_rate(self, it: int) -> float:
+        """CosineDecay(1e-3, decay_steps), train.py:128-130 [3P]."""
+        it = min(it, self.lr_decay_steps)
+        return self.base_lr * 0.5 * (1 + math.cos(math.pi * it / self.lr_decay_steps))
+
+    def on_epoch_begin(self, epoch, logs=None):   # models.py:239-240
+        self.epoch = epoch
+
+    def calculate_recon_loss(self, inputs, reconstruction, crop_output=False) -> torch.Tensor:
+        """models.py:242-250 -> [B]."""
+        x = self._as_input(inputs)
+        B = x.shape[0]
+        out = torch.empty(B, dtype=torch.float32, device=self.device)
+        ctx = Ctx(self.ps, self.dtype, training=False, record=False)
+        ops.bernoulli_nll(ctx, Var(reconstruction.to(torch.float32).contiguous(), False), x, out, 1.0 / B,
+                          crop=crop_output)
+        return out
+
+    def calculate_bn_loss(self) -> torch.Tensor:
+        """models.py:252-267."""
+        out = torch.zeros(1, dtype=torch.float32, device=self.device)
+        L.call("nvae_bn_absmax_fwd", L.ptr(self.ps.params), L.ptr(self.ps.bn_table),
+               len(self.ps.bn_loss_layers), float(self.sr_lambda), L.ptr(out), L.ptr(self.ps.bn_argmax))
+        return out[0]
+
+    def calculate_kl_loss(self, kl_all: torch.Tensor, balancing: bool, beta: float = 1.0) -> torch.Tensor:
+        """models.py:191-223 on a [G, B] matrix of per-group KL terms -> [B] (times beta)."""
+        G, B = kl_all.shape
+        hyper = torch.zeros(L.HY_SIZE, dtype=torch.float32, device=self.device)
+        hyper[L.HY_BETA] = beta
+        hyper[L.HY_BALANCE] = 1.0 if balancing else 0.0
+        am = torch.empty(G, dtype=torch.float32, device=self.device)
+        coeff = torch.empty(G, dtype=torch.float32, device=self.device)
+        out = torch.empty(B, dtype=torch.float32, device=self.device)
+        res = torch.empty(L.RES_SIZE, dtype=torch.float32, device=self.device)
+        zero = torch.zeros(B, dtype=torch.float32, device=self.device)
+        L.call("nvae_kl_absmean", L.ptr(kl_all), G, B, L.ptr(am))
+        L.call("nvae_loss_finalize", L.ptr(kl_all), L.ptr(am), L.ptr(self.alphas), G, B, L.ptr(zero), None,
+               L.ptr(hyper), L.ptr(coeff), L.ptr(out), L.ptr(res))
+        return out
+
+    # ------------------------------------------------------------------ training step
+    def _set_hyper(self):
+        beta = self.beta()
+        t = self.opt_iterations + 1
+        lr_t = self.learning_rate(self.opt_iterations) / (1 - ADAMAX_B1 ** t)
+        h = torch.zeros(L.HY_SIZE, dtype=torch.float32)
+        h[L.HY_LR], h[L.HY_BETA], h[L.HY_BALANCE] = lr_t, beta, 1.0 if beta < 1 else 0.0
+        self.hyper.copy_(h, non_blocking=False)
+
+    def _seg_forward(self, x: torch.Tensor, eps_list, spectral_norm=True):
+        """SN + forward + per-rank loss statistics.  Returns the context holding the tape."""
+        ps = self.ps
+        B = x.shape[0]
+        buf = self._buffers(B)
+        ps.begin_step()
+        ps.prepare_weights(spectral_norm=spectral_norm)
+        ctx = Ctx(ps, self.dtype, training=True, record=True)
+        self._bn_loss = ctx.zeros_f32(1)
+        nb = len(ps.bn_loss_layers)
+        if nb:
+            L.call("nvae_bn_absmax_fwd", L.ptr(ps.params), L.ptr(ps.bn_table), nb, float(self.sr_lambda),
+                   L.ptr(self._bn_loss), L.ptr(ps.bn_argmax))
+            ctx.tape.append(lambda: L.call("nvae_bn_absmax_bwd", L.ptr(ps.params), L.ptr(ps.grads),
+                                           L.ptr(ps.bn_table), L.ptr(ps.bn_argmax), nb, float(self.sr_lambda)))
+        logits = self._forward(ctx, x, eps_list)
+        ops.bernoulli_nll(ctx, logits, x, buf["recon"], 1.0 / B)
+        L.call("nvae_kl_absmean", L.ptr(buf["kl_all"]), self.n_groups, B, L.ptr(self.am))
+        self._logits = logits
+        return ctx
+
+    def _seg_backward(self, ctx: Ctx, B: int):
+        buf = self._buffers(B)
+        L.call("nvae_loss_finalize", L.ptr(buf["kl_all"]), L.ptr(self.am), L.ptr(self.alphas), self.n_groups,
+               B, L.ptr(buf["recon"]), L.ptr(self._bn_loss), L.ptr(self.hyper), L.ptr(self.coeff),
+               L.ptr(buf["kl_loss"]), L.ptr(self.results))
+        ctx.backward()
+
+    def _seg_update(self):
+        ps = self.ps
+        L.call("nvae_adamax", L.ptr(ps.params), L.ptr(ps.grads), L.ptr(ps.adam_m), L.ptr(ps.adam_u),
+               ps.params.numel(), L.ptr(self.hyper), ADAMAX_B1, ADAMAX_B2, ADAMAX_EPS)
+
+    def train_step(self, data, eps_list=None, spectral_norm=True, update=True):
+        """NVAE.train_step, models.py:100-135 (eager launch path).  Returns device tensors:
+        loss (scalar), reconstruction_loss [B], kl_loss [B] (already beta-scaled, Q11), bn_loss,
+        plus kl_per_group [G, B] (unscaled)."""
+        x = self._as_input(data)
+        B = x.shape[0]
+        self._set_hyper()
+        ctx = self._seg_forward(x, eps_list, spectral_norm)
+        if self.reducer is not None:
+            self.reducer.allreduce_mean_(self.am)
+        self._seg_backward(ctx, B)
+        if self.reducer is not None:
+            self.reducer.allreduce_grads_(self.ps.grads)
+        if update:
+            self._seg_update()
+            self.opt_iterations += 1
+        self.steps += 1
+        return self._step_outputs(B)
+
+    def _step_outputs(self, B):
+        buf = self._buffers(B)
+        return {"loss": self.results[L.RES_LOSS], "reconstruction_loss": buf["recon"],
+                "kl_loss": buf["kl_loss"], "bn_loss": self.results[L.RES_BN],
+                "kl_per_group": buf["kl_all"]}
+
+    # ------------------------------------------------------------------ hipGraph-replayed step
+    def capture_train_step(self, batch_shape, warmup: int = 2):
+        """Capture the training step into hipGraphs for a fixed batch shape.  The step is
+        [graph: SN + forward + loss stats] -> (all-reduce of the [G] KL statistic when DP)
+        -> [graph: loss + backward] -> (gradient all-reduce when DP) -> [graph: Adamax].
+        Host-side scalars (lr, beta) reach the kernels through the `hyper` device buffer, noise is
+        drawn in-graph from a device counter, so replays are exact continuations of training."""
+        B = int(batch_shape[0])
+        self._static_x = torch.zeros(tuple(batch_shape), dtype=self.dtype, device=self.device)
+        self._set_hyper()
+        side = torch.cuda.Stream(device=self.device)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                ctx = self._seg_forward(self._static_x, None)
+                self._seg_backward(ctx, B)
+                self._seg_update()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize(self.device)
+        pool = torch.cuda.graph_pool_handle()
+        g1, g2, g3 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g1, pool=pool):
+            ctx = self._seg_forward(self._static_x, None)
+        with torch.cuda.graph(g2, pool=pool):
+            self._seg_backward(ctx, B)
+        with torch.cuda.graph(g3, pool=pool):
+            self._seg_update()
+        self._plan = (g1, g2, g3, B)
+        return self
+
+    def train_step_graphed(self, data=None):
+        """Replay the captured step (data=None reuses the static input buffer contents)."""
+        g1, g2, g3, B = self._plan
+        if data is not None:
+            self._static_x.copy_(self._as_input(data))
+        self._set_hyper()
+        g1.replay()
+        if self.reducer is not None:
+            self.reducer.allreduce_mean_(self.am)
+        g2.replay()
+        if self.reducer is not None:
+            self.reducer.allreduce_grads_(self.ps.grads)
+        g3.replay()
+        self.opt_iterations += 1
+        self.steps += 1
+        return self._step_outputs(B)
+
+    # ------------------------------------------------------------------ sampling (models.py:137-189)
+    def sample(self, n_samples=16, temperature=1.0, greyscale=True, eps_list=None):
+        """Ancestral sampling.  Temperature scales z0's sigma only (Q8).  Returns
+        (images [B,H,W,C] f32 in [0,1], last_s, z1, z2) like the reference."""
+        ps = self.ps
+        B = n_samples
+        ps.begin_step()
+        ps.prepare_weights(spectral_norm=False)
+        ctx = Ctx(ps, self.dtype, training=False, record=False)
+        eps = self._draw_eps(ctx, B, eps_list)
+        buf = self._buffers(B)
+        dec = self.decoder
+        # group 0: mu = softclamp5(0) = 0, sigma = exp(softclamp5(0)) + 1e-2 = 1.01 (models.py:141-144)
+        zero_p = Var(torch.zeros((B,) + dec.z0_shape[:2] + (2 * self.n_latent_per_group,),
+                                 dtype=torch.float32, device=self.device), False)
+        eps0 = eps[0] * temperature if temperature != 1.0 else eps[0]
+        z = ops.sampler(ctx, zero_p, None, eps0, buf["kl_all"][0], self.coeff[0:1], self.hyper, 1.0 / B)
+        s = dec.tiled_h(ctx, B)
+        decoder_index = 0
+        last_s = None
+        last_params = None
+        for layer in dec.groups:
+            if isinstance(layer, DecoderSampleCombiner):
+                if decoder_index > 0:
+                    p = dec.sampler.get_params(ctx, dec.sampler.dec_sampler, decoder_index, s)
+                    # prior sample: mu = sc(mu_p), sigma = exp(sc(log_sigma_p)) + 1e-2 == the group-0
+                    # formula applied to the decoder's raw parameters (models.py:153-159)
+                    z = ops.sampler(ctx, p, None, eps[decoder_index], buf["kl_all"][decoder_index],
+                                    self.coeff[0:1], self.hyper, 1.0 / B)
+                    last_params = p
+                last_s = s
+                s = layer(ctx, s, z)
+                decoder_index += 1
+            elif isinstance(layer, list):
+                for cell in layer:
+                    s = cell(ctx, s)
+            else:
+                s = layer(ctx, s)
+        logits = self.postprocess(ctx, s).t
+        images = torch.sigmoid(logits) if greyscale else torch.bernoulli(torch.sigmoid(logits))
+        # z1, z2: two more draws from the last group's prior (models.py:175-176)
+        zs = []
+        for _ in range(2):
+            e = ops.randn(ctx, eps[-1].shape, self.seed, self.rng_counter)
+            src = last_params if last_params is not None else zero_p
+            zs.append(ops.sampler(ctx, src, None, e, buf["kl_all"][0], self.coeff[0:1], self.hyper, 1.0 / B).t)
+        return images, (last_s.t if last_s is not None else None), zs[0], zs[1]
+
+    def sample_with_z(self, z: torch.Tensor, s: torch.Tensor):
+        """models.py:181-189: decode from a fixed last-group z and its decoder state s."""
+        ps = self.ps
+        ps.begin_step()
+        ps.prepare_weights(spectral_norm=False)
+        ctx = Ctx(ps, self.dtype, training=False, record=False)
+        last = self.decoder.groups[-1]
+        out = last(ctx, Var(s.to(self.device, self.dtype).contiguous(), False),
+                   Var(z.to(self.device, self.dtype).contiguous(), False))
+        logits = self.postprocess(ctx, out).t
+        return torch.sigmoid(logits)

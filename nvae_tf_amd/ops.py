@@ -1,0 +1,349 @@
+"""Host-side operator layer: a minimal tape (explicit backward closures, no autograd engine) over
+the C-ABI kernels.  Every arithmetic op of the hot path is a libnvae_hip.so launch; torch supplies
+device buffers only.  Gradients accumulate through the kernels' own `accumulate` epilogues."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Callable, List, Optional, Tuple
+
+import torch
+
+from . import _lib as L
+from ._lib import call, ptr
+
+
+def same_pad(in_size: int, k: int, s: int) -> Tuple[int, int]:
+    """TF padding='same' (SURVEY Q6): low pad = total // 2."""
+    out = -(-in_size // s)
+    total = max((out - 1) * s + k - in_size, 0)
+    return total // 2, total - total // 2
+
+
+class Var:
+    """An NHWC activation and (lazily) its gradient."""
+    __slots__ = ("t", "g", "needs_grad")
+
+    def __init__(self, t: torch.Tensor, needs_grad: bool = True):
+        self.t = t
+        self.g: Optional[torch.Tensor] = None
+        self.needs_grad = needs_grad
+
+    @property
+    def shape(self):
+        return self.t.shape
+
+
+class Ctx:
+    """Per-step execution context: dtype, mode, tape, and the per-step zeroed f32 scratch pool."""
+
+    def __init__(self, ps, dtype: torch.dtype, training: bool, record: bool, zero_pool_floats: int = 0):
+        self.ps = ps
+        self.dtype = dtype
+        self.dt = L.dtype_code(dtype)
+        self.ve = 8 if dtype == torch.bfloat16 else 4
+        self.training = training
+        self.record = record
+        self.tape: List[Callable[[], None]] = []
+        self.dev = ps.params.device
+        self.zero_pool = ps.zero_pool
+        self.zero_cursor = ps.zero_reserved
+
+    # ---- memory -------------------------------------------------------------------------
+    def empty(self, shape, dtype=None) -> torch.Tensor:
+        return torch.empty(shape, dtype=dtype or self.dtype, device=self.dev)
+
+    def zeros_f32(self, n: int) -> torch.Tensor:
+        """A slice of the pool that is zeroed once per step (ParamStore.begin_step)."""
+        n_al = (n + 7) // 8 * 8
+        if self.zero_cursor + n_al > self.zero_pool.numel():
+            raise RuntimeError("zero pool exhausted: enlarge ParamStore.zero_pool")
+        out = self.zero_pool[self.zero_cursor:self.zero_cursor + n]
+        self.zero_cursor += n_al
+        return out
+
+    def grad_of(self, v: Var) -> Tuple[torch.Tensor, int]:
+        """Gradient buffer of v and whether the next writer must accumulate into it."""
+        if v.g is None:
+            v.g = torch.empty(v.t.shape, dtype=self.dtype, device=self.dev)
+            return v.g, 0
+        return v.g, 1
+
+    def backward(self):
+        for fn in reversed(self.tape):
+            fn()
+        self.tape.clear()
+
+
+# ------------------------------------------------------------------------------------------
+# elementwise
+# ------------------------------------------------------------------------------------------
+def affine(ctx: Ctx, x: torch.Tensor, a: float, b: float) -> Var:
+    """y = a*x + b on an input tensor (no gradient): preprocess.py:39."""
+    y = ctx.empty(x.shape)
+    call("nvae_unary_fwd", ctx.dt, L.OP_AFFINE, ptr(x), ptr(y), x.numel(), a, b)
+    return Var(y, needs_grad=False)
+
+
+def unary(ctx: Ctx, x: Var, op: int) -> Var:
+    y = Var(ctx.empty(x.t.shape), x.needs_grad)
+    call("nvae_unary_fwd", ctx.dt, op, ptr(x.t), ptr(y.t), x.t.numel(), 0.0, 0.0)
+    if ctx.record and x.needs_grad:
+        def bwd():
+            g, acc = ctx.grad_of(x)
+            call("nvae_unary_bwd", ctx.dt, op, ptr(x.t), ptr(y.g), ptr(g), x.t.numel(), acc)
+        ctx.tape.append(bwd)
+    return y
+
+
+def add_grad(ctx: Ctx, dst: Var, src_grad: torch.Tensor):
+    g, acc = ctx.grad_of(dst)
+    call("nvae_add", ctx.dt, ptr(g), ptr(src_grad), src_grad.numel(), acc)
+
+
+# ------------------------------------------------------------------------------------------
+# convolution
+# ------------------------------------------------------------------------------------------
+def _geom(B, Hin, Win, Cin, Hout, Wout, Cout, KH, KW, stride, pad_t, pad_l, div, exact, in_ld,
+          out_ld, res_ld) -> L.ConvGeom:
+    return L.ConvGeom(B, Hin, Win, Cin, Hout, Wout, Cout, KH, KW, stride, pad_t, pad_l, div, exact,
+                      in_ld, out_ld, res_ld)
+
+
+def conv2d(ctx: Ctx, x: Var, conv, *, stride: int = 1, up: int = 1, pad: Optional[Tuple[int, int]] = None,
+           out_hw: Optional[Tuple[int, int]] = None, c_off: int = 0, cin: Optional[int] = None,
+           bias: bool = True, out: Optional[Var] = None, out_coff: int = 0, accumulate: bool = False,
+           residual: Optional[Var] = None, out_f32: bool = False) -> Var:
+    """Conv2D(padding='same') (+ folded nearest upsample, + residual add).  `conv` is a
+    params.ConvParam.  c_off/cin select a row slice of a 1x1 kernel (concat-free
+    DecoderSampleCombiner, decoder.py:115-117); out/out_coff write a channel slice of an existing
+    tensor (concat-free SkipScaler, preprocess.py:65-74)."""
+    ps = ctx.ps
+    B, H, W, Cx = x.t.shape
+    k = conv.k
+    cin = conv.cin if cin is None else cin
+    assert cin <= Cx and (c_off == 0 and cin == conv.cin or k == 1)
+    Hu, Wu = H * up, W * up
+    if pad is None:
+        pad = (same_pad(Hu, k, stride)[0], same_pad(Wu, k, stride)[0])
+    if out_hw is None:
+        out_hw = (-(-Hu // stride), -(-Wu // stride))
+    Ho, Wo = out_hw
+    cout = conv.cout
+    if out is None:
+        out = Var(ctx.empty((B, Ho, Wo, cout), torch.float32 if out_f32 else None))
+    Cy = out.t.shape[3]
+    assert out.t.shape[:3] == (B, Ho, Wo) and out_coff + cout <= Cy
+    esz_out = out.t.element_size()
+    out_ptr = ptr(out.t) + out_coff * esz_out
+    res_ptr, res_ld = None, Cy
+    if accumulate:
+        res_ptr, res_ld = out_ptr, Cy
+        assert not out_f32
+    elif residual is not None:
+        assert residual.t.shape == (B, Ho, Wo, cout)
+        res_ptr, res_ld = ptr(residual.t), cout
+    bias_ptr = ptr(ps.view(conv.b)) if (bias and conv.b is not None) else None
+    ve = ctx.ve
+    g = _geom(B, H, W, cin, Ho, Wo, cout, k, k, stride, pad[0], pad[1], up, 0, Cx, Cy, res_ld)
+    fwd_mfma = cin % ve == 0 and Cx % ve == 0 and c_off % ve == 0 and conv.wf_off >= 0
+    if fwd_mfma:
+        wT = ptr(ps.wcopies) + (conv.wf_off + c_off) * ps.wcopies.element_size()
+        call("nvae_conv_gemm", ctx.dt, C.byref(g), ptr(x.t), wT, conv.wf_ld, bias_ptr, res_ptr, out_ptr,
+             int(out_f32))
+    else:
+        w = ptr(ps.view(conv.w)) + c_off * cout * 4
+        call("nvae_conv_direct", ctx.dt, C.byref(g), ptr(x.t), w, conv.cin * cout, cout, 1, 0, bias_ptr,
+             res_ptr, out_ptr, int(out_f32))
+
+    if ctx.record:
+        def bwd():
+            dy = out.g
+            assert dy is not None, f"no gradient reached conv {conv.name}"
+            esz = dy.element_size()
+            dy_ptr = ptr(dy) + out_coff * esz
+            # ---- weight / bias gradient
+            dw = ptr(ps.grads) + (conv.w.off + c_off * cout) * 4
+            db = (ptr(ps.grads) + conv.b.off * 4) if (bias and conv.b is not None) else None
+            gw = _geom(B, H, W, cin, Ho, Wo, cout, k, k, stride, pad[0], pad[1], up, 0, Cx, Cy, Cy)
+            w_mfma = (cin % ve == 0 and Cx % ve == 0 and cout % 8 == 0 and Cy % ve == 0
+                      and out_coff % ve == 0)
+            if w_mfma:
+                call("nvae_conv_wgrad", ctx.dt, C.byref(gw), ptr(x.t), dy_ptr, dw, cout)
+                if db is not None:
+                    call("nvae_colsum", ctx.dt, dy_ptr, B * Ho * Wo, cout, Cy, db)
+            else:
+                call("nvae_conv_direct_wgrad", ctx.dt, C.byref(gw), ptr(x.t), dy_ptr, dw, cout, db)
+            # ---- residual
+            if residual is not None and residual.needs_grad:
+                add_grad(ctx, residual, dy)
+            # ---- data gradient
+            if x.needs_grad:
+                if up == 1:
+                    dst, acc = ctx.grad_of(x)
+                else:
+                    dst, acc = ctx.empty((B, Hu, Wu, Cx)), 0
+                    assert cin == Cx
+                gd = _geom(B, Ho, Wo, cout, Hu, Wu, cin, k, k, 1, k - 1 - pad[0], k - 1 - pad[1],
+                           stride, 1, Cy, Cx, Cx)
+                d_mfma = (cout % ve == 0 and Cy % ve == 0 and out_coff % ve == 0 and conv.wd_off >= 0)
+                resid = ptr(dst) if acc else None
+                if cin != Cx and not acc:
+                    # partial-channel write into a fresh buffer is not expected on this path
+                    raise RuntimeError("conv2d backward: channel-sliced input must be accumulated")
+                if d_mfma:
+                    wD = ptr(ps.wcopies) + (conv.wd_off + c_off * conv.wd_ld) * ps.wcopies.element_size()
+                    call("nvae_conv_gemm", ctx.dt, C.byref(gd), dy_ptr, wD, conv.wd_ld, None, resid,
+                         ptr(dst), 0)
+                else:
+                    w = ptr(ps.view(conv.w)) + c_off * cout * 4
+                    call("nvae_conv_direct", ctx.dt, C.byref(gd), dy_ptr, w, conv.cin * cout, 1, cout, 1,
+                         None, resid, ptr(dst), 0)
+                if up != 1:
+                    gx, accx = ctx.grad_of(x)
+                    call("nvae_upsample_pool_bwd", ctx.dt, ptr(dst), ptr(gx), B, H, W, Cx, up, accx)
+        ctx.tape.append(bwd)
+    return out
+
+
+def dwconv5(ctx: Ctx, x: Var, dw) -> Var:
+    """DepthwiseConv2D((5,5), padding='same') with bias, decoder.py:130."""
+    ps = ctx.ps
+    B, H, W, Cc = x.t.shape
+    y = Var(ctx.empty(x.t.shape))
+    call("nvae_dwconv5", ctx.dt, ptr(x.t), ptr(ps.view(dw.w)), ptr(ps.view(dw.b)), ptr(y.t), B, H, W, Cc, 0, 0)
+    if ctx.record:
+        def bwd():
+            call("nvae_dwconv5_wgrad", ctx.dt, ptr(x.t), ptr(y.g), ptr(ps.grads) + dw.w.off * 4,
+                 ptr(ps.grads) + dw.b.off * 4, B, H, W, Cc)
+            g, acc = ctx.grad_of(x)
+            call("nvae_dwconv5", ctx.dt, ptr(y.g), ptr(ps.view(dw.w)), None, ptr(g), B, H, W, Cc, 1, acc)
+        ctx.tape.append(bwd)
+    return y
+
+
+# ------------------------------------------------------------------------------------------
+# BatchNorm (+ Swish)
+# ------------------------------------------------------------------------------------------
+BN_MOMENTUM = 0.05   # Keras semantics: fraction of the OLD moving statistic kept
+BN_EPS = 1e-5
+
+
+def bn_act(ctx: Ctx, x: Var, bn, act: int = L.ACT_NONE) -> Var:
+    ps = ctx.ps
+    B, H, W, Cc = x.t.shape
+    rows = B * H * W
+    coef = ctx.empty((4, Cc), torch.float32)   # scale, shift, mean, invstd
+    scale, shift, mean, invstd = (ptr(coef) + i * Cc * 4 for i in range(4))
+    gamma, beta = ptr(ps.view(bn.gamma)), ptr(ps.view(bn.beta))
+    rm, rv = ptr(ps.sview(bn.rm)), ptr(ps.sview(bn.rv))
+    if ctx.training:
+        sums = ctx.zeros_f32(2 * Cc)
+        call("nvae_bn_stats", ctx.dt, ptr(x.t), rows, Cc, ptr(sums))
+        call("nvae_bn_finalize", ptr(sums), rows, Cc, gamma, beta, rm, rv, BN_MOMENTUM, BN_EPS, scale,
+             shift, mean, invstd)
+    else:
+        call("nvae_bn_eval_prepare", gamma, beta, rm, rv, Cc, BN_EPS, scale, shift)
+    y = Var(ctx.empty(x.t.shape), x.needs_grad)
+    call("nvae_bn_apply", ctx.dt, ptr(x.t), ptr(y.t), rows, Cc, scale, shift, act)
+    if ctx.record:
+        assert ctx.training, "backward through inference-mode BN is not on the path"
+
+        def bwd():
+            dgamma = ptr(ps.grads) + bn.gamma.off * 4
+            dbeta = ptr(ps.grads) + bn.beta.off * 4
+            call("nvae_bn_bwd_reduce", ctx.dt, ptr(x.t), ptr(y.g), rows, Cc, scale, shift, mean, invstd,
+                 act, dgamma, dbeta)
+            if x.needs_grad:
+                g, acc = ctx.grad_of(x)
+                call("nvae_bn_bwd_apply", ctx.dt, ptr(x.t), ptr(y.g), ptr(g), rows, Cc, scale, shift, mean,
+                     invstd, act, dgamma, dbeta, acc)
+            _ = coef   # keep alive
+        ctx.tape.append(bwd)
+    return y
+
+
+# ------------------------------------------------------------------------------------------
+# Squeeze-Excitation + residual
+# ------------------------------------------------------------------------------------------
+def se_residual(ctx: Ctx, x: Var, se, skip: Var, skip_scale: float, branch_scale: float) -> Var:
+    """y = skip_scale*skip + branch_scale*SE(x)   (SURVEY Q3 for which side carries the 0.1)."""
+    ps = ctx.ps
+    B, H, W, Cc = x.t.shape
+    HW, Hd = H * W, se.hidden
+    pooled = ctx.zeros_f32(B * Cc) if True else None
+    gate = ctx.empty((B, Cc), torch.float32)
+    hidden = ctx.empty((B, Hd), torch.float32)
+    w1, b1, w2, b2 = (ptr(ps.view(p)) for p in (se.w1, se.b1, se.w2, se.b2))
+    call("nvae_se_pool", ctx.dt, ptr(x.t), B, HW, Cc, ptr(pooled))
+    call("nvae_se_gate", ptr(pooled), B, HW, Cc, Hd, w1, b1, w2, b2, ptr(gate), ptr(hidden))
+    y = Var(ctx.empty(x.t.shape))
+    call("nvae_se_apply", ctx.dt, ptr(x.t), ptr(skip.t), ptr(y.t), B, HW, Cc, ptr(gate), skip_scale,
+         branch_scale)
+    if ctx.record:
+        r = ctx.zeros_f32(B * Cc)
+
+        def bwd():
+            dpool = ctx.empty((B, Cc), torch.float32)
+            call("nvae_se_bwd_reduce", ctx.dt, ptr(x.t), ptr(y.g), B, HW, Cc, ptr(r))
+            gp = ptr(ps.grads)
+            call("nvae_se_gate_bwd", ptr(r), ptr(pooled), ptr(gate), ptr(hidden), B, HW, Cc, Hd, w1, w2,
+                 branch_scale, gp + se.w1.off * 4, gp + se.b1.off * 4, gp + se.w2.off * 4,
+                 gp + se.b2.off * 4, ptr(dpool))
+            gx, accx = ctx.grad_of(x)
+            if skip.needs_grad:
+                gs, accs = ctx.grad_of(skip)
+                gs_ptr = ptr(gs)
+            else:
+                gs_ptr, accs = None, 0
+            call("nvae_se_bwd_apply", ctx.dt, ptr(y.g), ptr(gate), ptr(dpool), ptr(gx), gs_ptr, B, HW, Cc,
+                 skip_scale, branch_scale, accx, accs)
+        ctx.tape.append(bwd)
+    return y
+
+
+# ------------------------------------------------------------------------------------------
+# latent hierarchy
+# ------------------------------------------------------------------------------------------
+def sampler(ctx: Ctx, enc_p: Var, dec_p: Optional[Var], eps: torch.Tensor, kl_out: torch.Tensor,
+            coeff: torch.Tensor, hyper: torch.Tensor, inv_batch: float,
+            logq: Optional[torch.Tensor] = None, logp: Optional[torch.Tensor] = None,
+            mu_sigma: Optional[torch.Tensor] = None) -> Var:
+    """Sampler.call + this group's KL (+ log q / log p): common.py:76-102, models.py:197-201."""
+    B, H, W, L2 = enc_p.t.shape
+    Lc = L2 // 2
+    assert enc_p.t.dtype == torch.float32 and eps.dtype == torch.float32 and eps.shape == (B, H, W, Lc)
+    z = Var(ctx.empty((B, H, W, Lc)))
+    dp = ptr(dec_p.t) if dec_p is not None else None
+    call("nvae_sampler_fwd", ctx.dt, ptr(enc_p.t), dp, ptr(eps), ptr(z.t), ptr(kl_out), ptr(logq), ptr(logp),
+         ptr(mu_sigma), B, H * W, Lc)
+    if ctx.record:
+        def bwd():
+            enc_p.g = ctx.empty(enc_p.t.shape)
+            d_dec = None
+            if dec_p is not None:
+                dec_p.g = ctx.empty(dec_p.t.shape)
+                d_dec = ptr(dec_p.g)
+            call("nvae_sampler_bwd", ctx.dt, ptr(enc_p.t), dp, ptr(eps), ptr(z.g), ptr(coeff), ptr(hyper),
+                 inv_batch, ptr(enc_p.g), d_dec, B, H * W, Lc)
+        ctx.tape.append(bwd)
+    return z
+
+
+def bernoulli_nll(ctx: Ctx, logits: Var, x: torch.Tensor, recon_out: torch.Tensor, inv_batch: float,
+                  crop: bool = False):
+    """calculate_recon_loss, models.py:242-250."""
+    B, H, W, Cc = logits.t.shape
+    assert logits.t.dtype == torch.float32
+    call("nvae_bernoulli_fwd", ctx.dt, ptr(logits.t), ptr(x), ptr(recon_out), B, H, W, Cc, int(crop))
+    if ctx.record:
+        def bwd():
+            logits.g = ctx.empty(logits.t.shape)
+            call("nvae_bernoulli_bwd", ctx.dt, ptr(logits.t), ptr(x), ptr(logits.g), logits.t.numel(),
+                 inv_batch)
+        ctx.tape.append(bwd)
+
+
+def randn(ctx: Ctx, shape, seed: int, counter: torch.Tensor) -> torch.Tensor:
+    out = ctx.empty(shape, torch.float32)
+    call("nvae_randn", ptr(out), out.numel(), seed, ptr(counter))
+    return out

@@ -1,0 +1,469 @@
+"""GPU parity tests of the individual kernels, called through the C ABI (ctypes), against fp64
+PyTorch-CPU references of the same op.  Tolerances: f32 kernels 2e-4 relative to the output scale
+(f32 MFMA is an exact fmaf chain, the slack covers summation order); bf16 kernels 2e-2."""
+import ctypes as C
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+TOL = {torch.float32: 2e-4, torch.bfloat16: 2.5e-2}
+DTYPES = [torch.float32, torch.bfloat16]
+
+
+def rel_err(a, b):
+    a = a.detach().double().cpu()
+    b = b.detach().double().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-12))
+
+
+def q(t, dtype):
+    """Quantise a reference tensor to what the kernel will actually read."""
+    return t.to(dtype).double()
+
+
+def make_ctx(ps, dtype, training=True, record=True):
+    from nvae_tf_amd.ops import Ctx
+    ps.begin_step()
+    ps.prepare_weights(spectral_norm=False)
+    return Ctx(ps, dtype, training=training, record=record)
+
+
+def ref_conv(x, w, b, stride, pad, up, out_hw):
+    """fp64 reference: nearest-upsample, explicit (top,left) padding, HWIO weights, NHWC."""
+    if up > 1:
+        x = x.repeat_interleave(up, dim=1).repeat_interleave(up, dim=2)
+    kh, kw = w.shape[0], w.shape[1]
+    Ho, Wo = out_hw
+    H, W = x.shape[1], x.shape[2]
+    pb = (Ho - 1) * stride + kh - H - pad[0]
+    pr = (Wo - 1) * stride + kw - W - pad[1]
+    xn = x.permute(0, 3, 1, 2)
+    xn = F.pad(xn, (pad[1], max(pr, 0), pad[0], max(pb, 0))) if min(pad) >= 0 else xn
+    if min(pad) < 0:   # negative pad = crop from the top/left (SkipScaler shifts)
+        xn = xn[:, :, -pad[0]:, -pad[1]:]
+        pb = (Ho - 1) * stride + kh - xn.shape[2]
+        pr = (Wo - 1) * stride + kw - xn.shape[3]
+        xn = F.pad(xn, (0, max(pr, 0), 0, max(pb, 0)))
+    y = F.conv2d(xn.contiguous(), w.permute(3, 2, 0, 1).contiguous(), b, stride=stride)
+    return y.permute(0, 2, 3, 1)[:, :Ho, :Wo, :]
+
+
+CONV_CASES = [
+    # k, cin, cout, stride, up, H, B, pad(None=same), bias, residual
+    dict(k=3, cin=16, cout=24, stride=1, up=1, H=8, B=2),
+    dict(k=5, cin=48, cout=48, stride=1, up=1, H=6, B=3),
+    dict(k=3, cin=16, cout=32, stride=2, up=1, H=8, B=2),
+    dict(k=3, cin=32, cout=16, stride=1, up=2, H=4, B=2),
+    dict(k=1, cin=64, cout=200, stride=1, up=1, H=16, B=2),
+    dict(k=1, cin=16, cout=8, stride=2, up=1, H=8, B=2, pad=(-1, -1)),
+    dict(k=3, cin=24, cout=40, stride=1, up=1, H=4, B=5, residual=True),
+    dict(k=5, cin=192, cout=192, stride=1, up=1, H=8, B=2, bias=False),
+    dict(k=3, cin=1, cout=16, stride=1, up=1, H=8, B=2),          # direct path (stem)
+    dict(k=3, cin=16, cout=1, stride=1, up=1, H=8, B=2),          # direct dgrad/wgrad (logit head)
+    dict(k=1, cin=20, cout=32, stride=1, up=1, H=4, B=4),         # latent half of the combiner
+]
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: "k{k}_ci{cin}_co{cout}_s{stride}_u{up}_H{H}".format(**c))
+def test_conv_fwd_bwd(lib, dev, dtype, case):
+    from nvae_tf_amd import ops
+    from nvae_tf_amd.ops import Var
+    from nvae_tf_amd.params import ParamStore
+    k, cin, cout, stride, up, H, B = (case[n] for n in ("k", "cin", "cout", "stride", "up", "H", "B"))
+    use_bias = case.get("bias", True)
+    g = torch.Generator().manual_seed(1234)
+    ps = ParamStore(seed=3)
+    conv = ps.conv("c", k, cin, cout, bias=use_bias)
+    ps.finalize(dev, dtype, zero_pool_floats=1 << 16)
+    if use_bias:
+        ps.view(conv.b).copy_(torch.randn(cout, generator=g))
+    x = torch.randn(B, H, H, cin, generator=g)
+    Hu = H * up
+    pad = case.get("pad")
+    if pad is None:
+        pad = (ops.same_pad(Hu, k, stride)[0],) * 2
+        Ho = -(-Hu // stride)
+    else:
+        Ho = (H + 1) // 2
+    res = torch.randn(B, Ho, Ho, cout, generator=g) if case.get("residual") else None
+    dy = torch.randn(B, Ho, Ho, cout, generator=g)
+
+    # ---- reference (on inputs quantised as the kernel sees them)
+    w64 = q(ps.get("c.w").cpu(), dtype).requires_grad_(True)
+    b64 = ps.view(conv.b).cpu().double().requires_grad_(True) if use_bias else None
+    x64 = q(x, dtype).requires_grad_(True)
+    y_ref = ref_conv(x64, w64, b64, stride, pad, up, (Ho, Ho))
+    if res is not None:
+        y_ref = y_ref + q(res, dtype)
+    dy64 = q(dy, dtype)
+    grads = torch.autograd.grad(y_ref, [x64, w64] + ([b64] if use_bias else []), dy64)
+
+    # ---- kernels
+    ctx = make_ctx(ps, dtype)
+    xv = Var(x.to(dev, dtype))
+    rv = Var(res.to(dev, dtype)) if res is not None else None
+    kw = dict(stride=stride, up=up, residual=rv, bias=use_bias)
+    if case.get("pad") is not None:
+        kw.update(pad=pad, out_hw=(Ho, Ho))
+    y = ops.conv2d(ctx, xv, conv, **kw)
+    y.g = dy.to(dev, dtype)
+    ctx.backward()
+    torch.cuda.synchronize()
+    tol = TOL[dtype]
+    assert rel_err(y.t, y_ref) < tol
+    assert rel_err(xv.g, grads[0]) < tol
+    assert rel_err(ps.get_grad("c.w"), grads[1]) < tol
+    if use_bias:
+        assert rel_err(ps.get_grad("c.b"), grads[2]) < tol
+    if rv is not None:
+        assert rel_err(rv.g, dy64) < tol
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+def test_conv_channel_slices(lib, dev, dtype):
+    """Concat-free DecoderSampleCombiner (row slices + accumulate) and SkipScaler (output slices)."""
+    from nvae_tf_amd import ops
+    from nvae_tf_amd.ops import Var
+    from nvae_tf_amd.params import ParamStore
+    from nvae_tf_amd.decoder import DecoderSampleCombiner
+    from nvae_tf_amd.preprocess import SkipScaler
+    g = torch.Generator().manual_seed(7)
+    ps = ParamStore(seed=5)
+    comb = DecoderSampleCombiner(ps, "comb", 32, 20, 48)
+    skips = {40: SkipScaler(ps, "skip40", 16, 40), 64: SkipScaler(ps, "skip64", 16, 64)}
+    ps.finalize(dev, dtype, zero_pool_floats=1 << 16)
+    B, H = 3, 4
+    x, z = torch.randn(B, H, H, 32, generator=g), torch.randn(B, H, H, 20, generator=g)
+    dy = torch.randn(B, H, H, 48, generator=g)
+    w = q(ps.get("comb.conv.w").cpu(), dtype).requires_grad_(True)
+    x64, z64 = q(x, dtype).requires_grad_(True), q(z, dtype).requires_grad_(True)
+    y_ref = ref_conv(torch.cat((x64, z64), 3), w, ps.get("comb.conv.b").cpu().double(), 1, (0, 0), 1, (H, H))
+    gr = torch.autograd.grad(y_ref, [x64, z64, w], q(dy, dtype))
+    ctx = make_ctx(ps, dtype)
+    xv, zv = Var(x.to(dev, dtype)), Var(z.to(dev, dtype))
+    y = comb(ctx, xv, zv)
+    y.g = dy.to(dev, dtype)
+    ctx.backward()
+    tol = TOL[dtype]
+    assert rel_err(y.t, y_ref) < tol
+    assert rel_err(xv.g, gr[0]) < tol and rel_err(zv.g, gr[1]) < tol
+    assert rel_err(ps.get_grad("comb.conv.w"), gr[2]) < tol
+
+    # SkipScaler: 40 channels = unaligned slices (scalar kernels), 64 = aligned (MFMA kernels)
+    H = 8
+    for nch, skip in skips.items():
+        name = f"skip{nch}"
+        x = torch.randn(B, H, H, 16, generator=g)
+        dy = torch.randn(B, H // 2, H // 2, nch, generator=g)
+        x64 = q(x, dtype).requires_grad_(True)
+        o = x64 * torch.sigmoid(x64)
+        if dtype == torch.bfloat16:
+            o = o + (o.to(dtype).double() - o).detach()   # the kernel stores swish(x) in bf16
+        views = [o, o[:, 1:, 1:, :], o[:, :, 1:, :], o[:, 1:, :, :]]
+        ws = [q(ps.get(f"{name}.conv{i + 1}.w").cpu(), dtype).requires_grad_(True) for i in range(4)]
+        bs = [ps.get(f"{name}.conv{i + 1}.b").cpu().double() for i in range(4)]
+        parts = [ref_conv(v, w_, b_, 2, (0, 0), 1, (H // 2, H // 2)) for v, w_, b_ in zip(views, ws, bs)]
+        y_ref = torch.cat(parts, 3)
+        gr = torch.autograd.grad(y_ref, [x64] + ws, q(dy, dtype))
+        ctx = make_ctx(ps, dtype)
+        xv = Var(x.to(dev, dtype))
+        y = skip(ctx, xv)
+        y.g = dy.to(dev, dtype)
+        ctx.backward()
+        assert rel_err(y.t, y_ref) < tol, nch
+        assert rel_err(xv.g, gr[0]) < 2 * tol, nch
+        for i in range(4):
+            assert rel_err(ps.get_grad(f"{name}.conv{i + 1}.w"), gr[1 + i]) < tol, (nch, i)
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("act", [0, 1], ids=["none", "swish"])
+@pytest.mark.parametrize("shape", [(4, 4, 4, 32), (3, 8, 8, 192), (2, 4, 4, 1536), (5, 16, 16, 64)])
+def test_bn_act(lib, dev, dtype, act, shape):
+    from nvae_tf_amd import ops
+    from nvae_tf_amd.ops import Var
+    from nvae_tf_amd.params import ParamStore
+    g = torch.Generator().manual_seed(11)
+    C_ = shape[3]
+    ps = ParamStore(seed=1)
+    bn = ps.bn("bn", C_)
+    ps.finalize(dev, dtype, zero_pool_floats=1 << 16)
+    ps.get("bn.gamma").copy_(torch.rand(C_, generator=g) + 0.5)
+    ps.get("bn.beta").copy_(torch.randn(C_, generator=g) * 0.3)
+    x = torch.randn(shape, generator=g) * 1.5 + 0.4
+    dy = torch.randn(shape, generator=g)
+    x64 = q(x, dtype).requires_grad_(True)
+    gam = ps.get("bn.gamma").cpu().double().requires_grad_(True)
+    bet = ps.get("bn.beta").cpu().double().requires_grad_(True)
+    mean, var = x64.mean((0, 1, 2)), x64.var((0, 1, 2), unbiased=False)
+    pre = (x64 - mean) * torch.rsqrt(var + 1e-5) * gam + bet
+    y_ref = pre * torch.sigmoid(pre) if act else pre
+    gr = torch.autograd.grad(y_ref, [x64, gam, bet], q(dy, dtype))
+    ctx = make_ctx(ps, dtype)
+    xv = Var(x.to(dev, dtype))
+    y = ops.bn_act(ctx, xv, bn, act)
+    y.g = dy.to(dev, dtype)
+    ctx.backward()
+    tol = TOL[dtype]
+    assert rel_err(y.t, y_ref) < tol
+    assert rel_err(xv.g, gr[0]) < 2 * tol
+    assert rel_err(ps.get_grad("bn.gamma"), gr[1]) < tol
+    assert rel_err(ps.get_grad("bn.beta"), gr[2]) < tol
+    # Keras moving statistics: moving = 0.05*moving + 0.95*batch
+    assert rel_err(ps.get_state("bn.rm"), 0.95 * mean) < 1e-4
+    assert rel_err(ps.get_state("bn.rv"), 0.05 + 0.95 * var) < 1e-4
+    # inference mode uses the moving statistics
+    ctx = make_ctx(ps, dtype, training=False, record=False)
+    y2 = ops.bn_act(ctx, Var(x.to(dev, dtype), False), bn, act)
+    rm, rv = ps.get_state("bn.rm").cpu().double(), ps.get_state("bn.rv").cpu().double()
+    pre = (x64 - rm) * torch.rsqrt(rv + 1e-5) * gam + bet
+    assert rel_err(y2.t, pre * torch.sigmoid(pre) if act else pre) < tol
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("shape,ss,bs", [((3, 8, 8, 128), 0.1, 1.0), ((4, 4, 4, 256), 1.0, 0.1), ((2, 32, 32, 32), 1.0, 0.1)])
+def test_se_residual(lib, dev, dtype, shape, ss, bs):
+    from nvae_tf_amd import ops
+    from nvae_tf_amd.ops import Var
+    from nvae_tf_amd.params import ParamStore
+    g = torch.Generator().manual_seed(13)
+    C_ = shape[3]
+    ps = ParamStore(seed=2)
+    se = ps.se("se", C_)
+    ps.finalize(dev, dtype, zero_pool_floats=1 << 16)
+    ps.get("se.b1").copy_(torch.randn(se.hidden, generator=g) * 0.1 + 0.1)
+    ps.get("se.b2").copy_(torch.randn(C_, generator=g) * 0.1)
+    x, skip, dy = (torch.randn(shape, generator=g) for _ in range(3))
+    x64, s64 = q(x, dtype).requires_grad_(True), q(skip, dtype).requires_grad_(True)
+    P = {n: ps.get("se." + n).cpu().double().requires_grad_(True) for n in ("w1", "b1", "w2", "b2")}
+    p = x64.mean((1, 2))
+    h = torch.relu(p @ P["w1"] + P["b1"])
+    gate = torch.sigmoid(h @ P["w2"] + P["b2"])
+    y_ref = ss * s64 + bs * x64 * gate[:, None, None, :]
+    gr = torch.autograd.grad(y_ref, [x64, s64, P["w1"], P["b1"], P["w2"], P["b2"]], q(dy, dtype))
+    ctx = make_ctx(ps, dtype)
+    xv, sv = Var(x.to(dev, dtype)), Var(skip.to(dev, dtype))
+    y = ops.se_residual(ctx, xv, se, sv, ss, bs)
+    y.g = dy.to(dev, dtype)
+    ctx.backward()
+    tol = TOL[dtype]
+    assert rel_err(y.t, y_ref) < tol
+    assert rel_err(xv.g, gr[0]) < tol and rel_err(sv.g, gr[1]) < tol
+    for i, n in enumerate(("w1", "b1", "w2", "b2")):
+        assert rel_err(ps.get_grad("se." + n), gr[2 + i]) < 4 * tol, n
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+def test_dwconv5(lib, dev, dtype):
+    from nvae_tf_amd import ops
+    from nvae_tf_amd.ops import Var
+    from nvae_tf_amd.params import ParamStore
+    g = torch.Generator().manual_seed(17)
+    B, H, C_ = 3, 8, 96
+    ps = ParamStore(seed=2)
+    dw = ps.dw("dw", C_)
+    ps.finalize(dev, dtype, zero_pool_floats=1 << 16)
+    ps.get("dw.b").copy_(torch.randn(C_, generator=g))
+    x, dy = torch.randn(B, H, H, C_, generator=g), torch.randn(B, H, H, C_, generator=g)
+    x64 = q(x, dtype).requires_grad_(True)
+    w64 = ps.get("dw.w").cpu().double().requires_grad_(True)
+    b64 = ps.get("dw.b").cpu().double().requires_grad_(True)
+    xn = F.pad(x64.permute(0, 3, 1, 2), (2, 2, 2, 2))
+    y_ref = F.conv2d(xn, w64.permute(2, 0, 1).unsqueeze(1).contiguous(), b64, groups=C_).permute(0, 2, 3, 1)
+    gr = torch.autograd.grad(y_ref, [x64, w64, b64], q(dy, dtype))
+    ctx = make_ctx(ps, dtype)
+    xv = Var(x.to(dev, dtype))
+    y = ops.dwconv5(ctx, xv, dw)
+    y.g = dy.to(dev, dtype)
+    ctx.backward()
+    tol = TOL[dtype]
+    assert rel_err(y.t, y_ref) < tol and rel_err(xv.g, gr[0]) < tol
+    assert rel_err(ps.get_grad("dw.w"), gr[1]) < tol and rel_err(ps.get_grad("dw.b"), gr[2]) < tol
+
+
+def _softclamp5(x):
+    return 5.0 * torch.tanh(x / 5.0)
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("group0", [True, False])
+def test_sampler_kl(lib, dev, dtype, group0):
+    from nvae_tf_amd import ops, _lib as L
+    from nvae_tf_amd.ops import Var
+    from nvae_tf_amd.params import ParamStore
+    g = torch.Generator().manual_seed(19)
+    B, H, Lc = 5, 4, 20
+    ps = ParamStore(seed=2)
+    ps.bn("dummy", 8)
+    ps.finalize(dev, dtype, zero_pool_floats=1 << 16)
+    enc = torch.randn(B, H, H, 2 * Lc, generator=g) * 2
+    dec = torch.randn(B, H, H, 2 * Lc, generator=g) * 2
+    eps = torch.randn(B, H, H, Lc, generator=g)
+    dz = torch.randn(B, H, H, Lc, generator=g)
+    beta, coeff, inv_b = 0.7, 1.3, 1.0 / B
+    e64 = enc.double().requires_grad_(True)
+    d64 = dec.double().requires_grad_(True)
+    a, b_ = e64[..., :Lc], e64[..., Lc:]
+    if group0:
+        mq, sq = _softclamp5(a), torch.exp(_softclamp5(b_)) + 1e-2
+        mp, sp = torch.zeros_like(mq), torch.ones_like(sq)
+    else:
+        m, s = d64[..., :Lc], d64[..., Lc:]
+        mp, sp = _softclamp5(m), torch.exp(_softclamp5(s)) + 1e-2
+        mq, sq = _softclamp5(a + m), torch.exp(_softclamp5(b_ + s)) + 1e-2
+    z_ref = mq + eps.double() * sq
+    t1, t2 = (mq - mp) / sp, sq / sp
+    kl_ref = (0.5 * (t1 * t1 + t2 * t2) - 0.5 - torch.log(t2)).sum((1, 2, 3))
+    lq_ref = (-0.5 * ((z_ref - mq) / sq) ** 2 - 0.5 * math.log(2 * math.pi) - torch.log(sq)).sum((1, 2, 3))
+    lp_ref = (-0.5 * ((z_ref - mp) / sp) ** 2 - 0.5 * math.log(2 * math.pi) - torch.log(sp)).sum((1, 2, 3))
+    total = (z_ref * q(dz, dtype)).sum() + beta * coeff * inv_b * kl_ref.sum()
+    gr = torch.autograd.grad(total, [e64] + ([] if group0 else [d64]))
+    ctx = make_ctx(ps, dtype)
+    hyper = torch.zeros(L.HY_SIZE, device=dev)
+    hyper[L.HY_BETA] = beta
+    cf = torch.full((1,), coeff, device=dev)
+    kl = torch.zeros(B, device=dev)
+    lq, lp = torch.zeros(B, device=dev), torch.zeros(B, device=dev)
+    ms = torch.zeros(4, B, H, H, Lc, device=dev)
+    ev = Var(enc.to(dev))
+    dv = None if group0 else Var(dec.to(dev))
+    z = ops.sampler(ctx, ev, dv, eps.to(dev), kl, cf, hyper, inv_b, lq, lp, ms)
+    z.g = dz.to(dev, dtype)
+    ctx.backward()
+    tol = TOL[dtype]
+    assert rel_err(z.t, z_ref) < tol
+    assert rel_err(kl, kl_ref) < 1e-4 and rel_err(lq, lq_ref) < 1e-4 and rel_err(lp, lp_ref) < 1e-4
+    assert rel_err(ms[0], mq) < 1e-5 and rel_err(ms[1], sq) < 1e-5 and rel_err(ms[3], sp) < 1e-5
+    assert rel_err(ev.g, gr[0]) < tol
+    if not group0:
+        assert rel_err(dv.g, gr[1]) < tol
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+def test_bernoulli_and_loss(lib, dev, dtype):
+    from nvae_tf_amd import ops, _lib as L
+    from nvae_tf_amd.ops import Var
+    from nvae_tf_amd.params import ParamStore
+    g = torch.Generator().manual_seed(23)
+    B = 6
+    ps = ParamStore(seed=2)
+    ps.bn("dummy", 8)
+    ps.finalize(dev, dtype, zero_pool_floats=1 << 16)
+    logits = torch.randn(B, 32, 32, 1, generator=g) * 3
+    x = (torch.rand(B, 32, 32, 1, generator=g) < 0.2).float()
+    l64 = logits.double().requires_grad_(True)
+    rec_ref = (F.softplus(l64) - x.double() * l64).sum((1, 2, 3))
+    gr = torch.autograd.grad(rec_ref.mean(), l64)[0]
+    ctx = make_ctx(ps, dtype)
+    lv = Var(logits.to(dev))
+    rec = torch.zeros(B, device=dev)
+    ops.bernoulli_nll(ctx, lv, x.to(dev, dtype), rec, 1.0 / B)
+    ctx.backward()
+    assert rel_err(rec, rec_ref) < 1e-5
+    assert rel_err(lv.g, gr) < TOL[dtype]
+    ctx = make_ctx(ps, dtype, record=False)
+    ops.bernoulli_nll(ctx, lv, x.to(dev, dtype), rec, 1.0 / B, crop=True)
+    crop_ref = (F.softplus(l64) - x.double() * l64)[:, 2:30, 2:30].sum((1, 2, 3))
+    assert rel_err(rec, crop_ref) < 1e-5
+    # KL balancing (models.py:204-218) through nvae_kl_absmean + nvae_loss_finalize
+    G = 7
+    kl_all = torch.rand(G, B, generator=g) * 10
+    alphas = torch.tensor([1., 1, 1, 1, 8, 8, 8])
+    beta = 0.35
+    c = kl_all.double().abs().mean(1) + 0.01
+    c = c / alphas.double() * c.sum()
+    c = c / c.mean()
+    kl_ref = beta * (kl_all.double() * c[:, None]).sum(0)
+    am = torch.zeros(G, device=dev); coeff = torch.zeros(G, device=dev)
+    klb = torch.zeros(B, device=dev); res = torch.zeros(L.RES_SIZE, device=dev)
+    hyper = torch.zeros(L.HY_SIZE, device=dev); hyper[L.HY_BETA] = beta; hyper[L.HY_BALANCE] = 1
+    bn = torch.full((1,), 0.88, device=dev)
+    L.call("nvae_kl_absmean", L.ptr(kl_all.to(dev)), G, B, L.ptr(am))
+    kd = kl_all.to(dev)
+    L.call("nvae_loss_finalize", L.ptr(kd), L.ptr(am), L.ptr(alphas.to(dev)), G, B, L.ptr(rec), L.ptr(bn),
+           L.ptr(hyper), L.ptr(coeff), L.ptr(klb), L.ptr(res))
+    assert rel_err(coeff, c) < 1e-5 and rel_err(klb, kl_ref) < 1e-5
+    want = float((crop_ref + kl_ref).mean()) + 0.88
+    assert abs(float(res[L.RES_LOSS]) - want) / abs(want) < 1e-5
+
+
+def test_spectral_norm_and_weight_prep(lib, dev):
+    from nvae_tf_amd.params import ParamStore
+    for dtype in DTYPES:
+        ps = ParamStore(seed=4)
+        convs = [ps.conv("a", 3, 16, 24), ps.conv("b", 1, 276, 64), ps.conv("c", 5, 8, 8, bias=False),
+                 ps.conv("d", 3, 1, 16)]
+        ps.finalize(dev, dtype, zero_pool_floats=1 << 16)
+        ref = {}
+        for c in convs:
+            w = ps.get(c.name + ".w").cpu().double()
+            u = ps.get_state(c.name + ".u").cpu().double().reshape(1, -1)
+            w2 = w.reshape(-1, c.cout)
+            v = u @ w2.t(); v = v / v.norm()
+            un = v @ w2; un = un / un.norm()
+            sigma = (v @ w2 @ un.t()).item()
+            ref[c.name] = (w / sigma, un.reshape(-1))
+        ps.begin_step()
+        ps.prepare_weights(spectral_norm=True)
+        torch.cuda.synchronize()
+        for c in convs:
+            wn, un = ref[c.name]
+            assert rel_err(ps.get(c.name + ".w"), wn) < 1e-5, c.name
+            assert rel_err(ps.get_state(c.name + ".u"), un) < 1e-5, c.name
+            K = c.k * c.k * c.cin
+            wf = ps.wcopies[c.wf_off:c.wf_off + c.cout * c.wf_ld].reshape(c.cout, c.wf_ld)[:, :K]
+            assert rel_err(wf, wn.reshape(K, c.cout).t()) < TOL[dtype], c.name
+            if c.wd_off >= 0:
+                wd = ps.wcopies[c.wd_off:c.wd_off + c.cin * c.wd_ld].reshape(c.cin, c.k, c.k, c.cout)
+                want = wn.flip(0, 1).permute(2, 0, 1, 3)
+                assert rel_err(wd, want) < TOL[dtype], c.name
+
+
+def test_adamax_unary_randn(lib, dev):
+    from nvae_tf_amd import _lib as L
+    g = torch.Generator().manual_seed(29)
+    n = 4096 + 8
+    p, gr = torch.randn(n, generator=g), torch.randn(n, generator=g)
+    m, u = torch.randn(n, generator=g) * 0.1, torch.rand(n, generator=g)
+    lr_t = 3e-3
+    m_ref = 0.9 * m.double() + 0.1 * gr.double()
+    u_ref = torch.maximum(0.999 * u.double(), gr.double().abs())
+    p_ref = p.double() - lr_t * m_ref / (u_ref + 1e-7)
+    hyper = torch.zeros(L.HY_SIZE, device=dev); hyper[L.HY_LR] = lr_t
+    pd, gd, md, ud = (t.to(dev) for t in (p, gr, m, u))
+    L.call("nvae_adamax", L.ptr(pd), L.ptr(gd), L.ptr(md), L.ptr(ud), n, L.ptr(hyper), 0.9, 0.999, 1e-7)
+    assert rel_err(pd, p_ref) < 1e-6 and rel_err(md, m_ref) < 1e-6 and rel_err(ud, u_ref) < 1e-6
+    for dtype in DTYPES:
+        x = torch.randn(1024, generator=g) * 2
+        xd = x.to(dev, dtype); y = torch.empty_like(xd); dx = torch.empty_like(xd)
+        dy = torch.randn(1024, generator=g).to(dev, dtype)
+        for op, f in ((L.OP_SWISH, lambda t: t * torch.sigmoid(t)), (L.OP_ELU, F.elu)):
+            x64 = xd.double().cpu().requires_grad_(True)
+            L.call("nvae_unary_fwd", L.dtype_code(dtype), op, L.ptr(xd), L.ptr(y), 1024, 0.0, 0.0)
+            L.call("nvae_unary_bwd", L.dtype_code(dtype), op, L.ptr(xd), L.ptr(dy), L.ptr(dx), 1024, 0)
+            ref = f(x64)
+            assert rel_err(y, ref) < TOL[dtype]
+            assert rel_err(dx, torch.autograd.grad(ref, x64, dy.double().cpu())[0]) < TOL[dtype]
+    out = torch.empty(1 << 20, device=dev)
+    ctr = torch.zeros(1, dtype=torch.int64, device=dev)
+    L.call("nvae_randn", L.ptr(out), out.numel(), 1234, L.ptr(ctr))
+    assert abs(float(out.mean())) < 5e-3 and abs(float(out.std()) - 1) < 5e-3
+    assert int(ctr[0]) == (1 << 20) // 4
+    out2 = torch.empty(1 << 20, device=dev)
+    L.call("nvae_randn", L.ptr(out2), out2.numel(), 1234, L.ptr(ctr))
+    assert float((out - out2).abs().max()) > 1.0   # the counter advanced: fresh noise
+
+
+def test_bad_arguments_fail_loudly(lib, dev):
+    from nvae_tf_amd import _lib as L
+    x = torch.zeros(16, device=dev)
+    with pytest.raises(RuntimeError, match="multiple of 8"):
+        L.call("nvae_unary_fwd", L.F32, L.OP_ELU, L.ptr(x), L.ptr(x), 12, 0.0, 0.0)
+    g = L.ConvGeom(1, 4, 4, 3, 4, 4, 8, 3, 3, 1, 1, 1, 1, 0, 3, 8, 8)
+    with pytest.raises(RuntimeError, match="conv_direct"):
+        L.call("nvae_conv_gemm", L.BF16, C.byref(g), L.ptr(x), L.ptr(x), 32, None, None, L.ptr(x), 0)
