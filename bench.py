@@ -1,0 +1,184 @@
+"""Headline benchmark: NVAE training throughput (images/s) on MNIST-shaped synthetic data.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Workload = BASELINE.json configs[1]: MNIST 28x28 zero-padded to 32x32, paper defaults (groups [5,10],
+2 residual cells per group, 20 latents per group), batch 128 PER GPU, bf16 activations / MFMA with
+f32 accumulation, f32 master weights, f32 BN statistics / KL / reconstruction.  One step = spectral
+norm power iteration + forward + ELBO + backward + (gradient all-reduce) + Adamax, replayed from
+hipGraphs.  Weak scaling: per-GPU batch fixed.  Prints ONE JSON line on rank 0."""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+TRAIN_FLOP_PER_IMG = 41.70e9     # 6 * 6949.4 M MAC (C2/C3)
+PEAK_BF16_TFLOPS = 2500.0        # MI355X_MICROARCH.md: dense bf16 MFMA peak
+BATCH_PER_GPU = 128
+
+
+def make_model(device, dtype, batch):
+    from nvae_tf_amd.models import NVAE
+    iters = 400 * (60000 // batch)
+    return NVAE(32, 32, 2, 2, 3, 20, 2, [5, 10], 2, 3, 0.01, 2, 400, iters, True, [batch, 32, 32, 1],
+                device=device, dtype=dtype, seed=1)
+
+
+def synthetic_batch(batch, seed, device):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.zeros(batch, 32, 32, 1)
+    x[:, 2:30, 2:30, :] = (torch.rand(batch, 28, 28, 1, generator=g) < 0.19).float()
+    return x.to(device)
+
+
+def time_dominant_kernel(model, batch, iters=20):
+    """Average launch duration of the dominant kernel (k_conv_gemm, the dense 5x5 implicit GEMM of
+    Postprocess) at its two shapes, with HIP events on the stream the kernel is launched on."""
+    from nvae_tf_amd import _lib as L
+    ps = model.ps
+    dev = model.device
+    out = []
+    for name, hw in (("post.cell1.conv5", 16), ("post.cell4.conv5", 32)):
+        conv = next(c for c in ps.convs if c.name == name)
+        x = torch.randn(batch, hw, hw, conv.cin, device=dev).to(model.dtype)
+        y = torch.empty(batch, hw, hw, conv.cout, device=dev, dtype=model.dtype)
+        g = L.ConvGeom(batch, hw, hw, conv.cin, hw, hw, conv.cout, 5, 5, 1, 2, 2, 1, 0, conv.cin, conv.cout, conv.cout)
+        wT = L.ptr(ps.wcopies) + conv.wf_off * ps.wcopies.element_size()
+
+        def launch():
+            L.call("nvae_conv_gemm", L.dtype_code(model.dtype), C.byref(g), L.ptr(x), wT, conv.wf_ld, None,
+                   None, L.ptr(y), 0)
+        for _ in range(3):
+            launch()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            launch()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / iters
+        flops = 2.0 * batch * hw * hw * 25 * conv.cin * conv.cout
+        out.append({"shape": f"B{batch}x{hw}x{hw} 5x5 {conv.cin}->{conv.cout}", "ms": ms,
+                    "tflops": flops / ms / 1e9})
+    return out
+
+
+def cpu_baseline(seconds_budget=20.0):
+    """The CPU oracle (PyTorch-CPU restatement of the reference arithmetic, f32, eager) timed on the
+    host cores: same model (C2), a bounded sample of the workload (batch 8)."""
+    from oracle.nvae_oracle import OracleConfig, OracleNVAE, synthetic_batch as sb
+    cores = min(os.cpu_count() or 1, 16)
+    torch.set_num_threads(cores)
+    b = 8
+    orc = OracleNVAE(OracleConfig(n_groups_per_scale=[5, 10], res_cells_per_group=2), dtype=torch.float32, seed=1)
+    x = sb(b, seed=1, dtype=torch.float32)
+    g = torch.Generator().manual_seed(2)
+    eps = [torch.randn(s, generator=g) for s in orc.eps_shapes(b)]
+    orc.train_step(x, eps)   # warm-up
+    t0 = time.time()
+    n = 0
+    while n < 2 or (time.time() - t0 < seconds_budget and n < 10):
+        orc.train_step(x, eps)
+        n += 1
+    dt = time.time() - t0
+    return {"value": b * n / dt, "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": f"{n} full train steps (SN + fwd + ELBO + bwd + Adamax) of the same model at batch {b}, f32, "
+                      f"PyTorch-CPU restatement of the reference (proxy for TF-CPU)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=BATCH_PER_GPU, help="per-GPU batch")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true")
+    args = ap.parse_args()
+
+    from nvae_tf_amd import parallel
+    rank, world, local = parallel.init_from_env()
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback for the hot path)"
+    device = torch.device(f"cuda:{local}")
+    torch.cuda.set_device(device)
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    import torch.distributed as dist
+
+    model = make_model(device, dtype, args.batch)
+    if world > 1:
+        model.reducer = parallel.GradReducer()
+        # identical replicas: broadcast rank 0's parameters and state
+        dist.broadcast(model.ps.params, 0)
+        dist.broadcast(model.ps.state, 0)
+    x = synthetic_batch(args.batch, 1 + rank, device)
+
+    if args.no_graph:
+        step = lambda: model.train_step(x)
+    else:
+        model.capture_train_step(x.shape, warmup=1)
+        model._static_x.copy_(x.to(dtype))
+        step = lambda: model.train_step_graphed(None)
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t[0])
+    loss = float(out["loss"])
+
+    if rank == 0:
+        value = args.batch * world * args.steps / dt
+        kern = time_dominant_kernel(model, args.batch)
+        avg_ms = sum(k["ms"] for k in kern) / len(kern)
+        flops_per_launch = 2.0 * args.batch * 943.7184e6   # both 5x5 shapes: 943.7 M MAC per image
+        achieved = flops_per_launch / avg_ms / 1e9
+        res = {
+            "metric": "train_images_per_sec", "value": value, "unit": "images/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16" if dtype == torch.bfloat16 else "f32", "data": "synthetic",
+            "config": {"workload": "MNIST 28x28 (zero-padded 32x32) NVAE paper defaults: groups [5,10], "
+                                   "2 cells/group, 20 latents/group; full train step "
+                                   "(SN + fwd + ELBO + bwd + Adamax)",
+                       "global_batch": args.batch * world, "batch_per_gpu": args.batch,
+                       "parallelism": f"dp{world}", "hip_graph": not args.no_graph},
+            "loss_nats": loss,
+            "e2e_mfma_frac": value / world * TRAIN_FLOP_PER_IMG / 1e12 / PEAK_BF16_TFLOPS,
+            "roofline": {"bound": "mfma", "kernel": "k_conv_gemm<bf16,192> (dense 5x5 implicit GEMM, Postprocess)",
+                         "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_BF16_TFLOPS, "traffic": None,
+                         "avg_launch_ms": avg_ms, "shapes": kern},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -68,9 +68,9 @@ int nvae_conv_gemm(int dtype, const NvaeConvGeom* g, const void* src, const void
                    const float* bias, const void* residual, void* out, int out_f32, void* stream);
 /* Weight gradient: dw[k, n] += sum_m gather(x)[m, k] * dy[m, n]  (f32 atomics, dw zeroed or
  * holding a partial sum).  g describes the FORWARD conv; dy has pixel stride g->out_ld.
- * dw_ld = row stride of dw in floats.                                                          */
+ * dw_ld = row stride of dw in floats.  db (may be NULL): db[n] += sum_m dy[m, n].               */
 int nvae_conv_wgrad(int dtype, const NvaeConvGeom* g, const void* x, const void* dy, float* dw,
-                    int dw_ld, void* stream);
+                    int dw_ld, float* db, void* stream);
 /* Scalar fallback for shapes the MFMA path does not take (Cin = 1, 20; Cout = 1).  w is the f32
  * master [KH, KW, *, *] addressed as w[tap*ws_tap + c*ws_c + n*ws_n] (tap order flipped if
  * flip != 0), so the same kernel serves forward and data-gradient.                              */
@@ -92,10 +92,13 @@ int nvae_dwconv5_wgrad(int dtype, const void* x, const void* dy, float* dw, floa
 
 /* ---- BatchNormalization(momentum=.05, eps=1e-5) (+Swish), encoder.py:91-103, decoder.py:125-146,
  *      postprocess.py:71,84,107-108, preprocess.py:88-89, common.py:148,165-166 ------------------- */
-int nvae_bn_stats(int dtype, const void* x, long rows, int C, float* sums /*[2C] zeroed*/, void* stream);
-/* mean/var from sums; scale = gamma*invstd, shift = beta - mean*scale; moving stats updated with
- * Keras semantics: moving = moving*momentum + batch*(1-momentum).                               */
-int nvae_bn_finalize(const float* sums, long rows, int C, const float* gamma, const float* beta,
+/* Row splits S used by the [rows, C] reductions; slabs passed as `partials` hold S*2*C floats.  */
+int nvae_reduce_splits(long rows, int C);
+/* partials[S][2][C] <- per-split (sum x, sum x^2).  No atomics, nothing needs zeroing.          */
+int nvae_bn_stats(int dtype, const void* x, long rows, int C, float* partials, void* stream);
+/* mean/var from the slab; scale = gamma*invstd, shift = beta - mean*scale; moving stats updated
+ * with Keras semantics: moving = moving*momentum + batch*(1-momentum).                          */
+int nvae_bn_finalize(const float* partials, long rows, int C, const float* gamma, const float* beta,
                      float* running_mean, float* running_var, float momentum, float eps,
                      float* scale, float* shift, float* mean, float* invstd, void* stream);
 int nvae_bn_eval_prepare(const float* gamma, const float* beta, const float* running_mean,
@@ -103,17 +106,21 @@ int nvae_bn_eval_prepare(const float* gamma, const float* beta, const float* run
                          void* stream);
 int nvae_bn_apply(int dtype, const void* x, void* y, long rows, int C, const float* scale,
                   const float* shift, int act, void* stream);
-/* dgamma/dbeta (f32, zeroed) receive sum(dpre * xhat), sum(dpre); dpre = dy * act'(pre).        */
+/* partials[S][2][C] <- per-split (sum dpre, sum dpre*x); dpre = dy * act'(scale*x + shift).      */
 int nvae_bn_bwd_reduce(int dtype, const void* x, const void* dy, long rows, int C, const float* scale,
-                       const float* shift, const float* mean, const float* invstd, int act,
-                       float* dgamma, float* dbeta, void* stream);
+                       const float* shift, int act, float* partials, void* stream);
+/* dgamma += sum dpre*xhat, dbeta += sum dpre; k0k1[2][C] = coefficients of
+ * dx = scale*dpre + k1*x + k0 (the batch-statistics terms of the BN gradient).                   */
+int nvae_bn_bwd_finalize(const float* partials, long rows, int C, const float* scale,
+                         const float* mean, const float* invstd, float* dgamma, float* dbeta,
+                         float* k0k1, void* stream);
 int nvae_bn_bwd_apply(int dtype, const void* x, const void* dy, void* dx, long rows, int C,
-                      const float* scale, const float* shift, const float* mean, const float* invstd,
-                      int act, const float* dgamma, const float* dbeta, int accumulate, void* stream);
+                      const float* scale, const float* shift, const float* k0k1, int act,
+                      int accumulate, void* stream);
 
 /* ---- SqueezeExcitation + residual, common.py:127-142 with encoder.py:107 / decoder.py:147 /
  *      preprocess.py:107 / postprocess.py:58:   y = skip_scale*skip + branch_scale*(x * gate) ----- */
-int nvae_se_pool(int dtype, const void* x, int B, int HW, int C, float* pooled_sum /*[B,C] zeroed*/,
+int nvae_se_pool(int dtype, const void* x, int B, int HW, int C, float* pooled_sum /*[B,C]*/,
                  void* stream);
 int nvae_se_gate(const float* pooled_sum, int B, int HW, int C, int Hd, const float* w1,
                  const float* b1, const float* w2, const float* b2, float* gate, float* hidden,
@@ -121,10 +128,11 @@ int nvae_se_gate(const float* pooled_sum, int B, int HW, int C, int Hd, const fl
 int nvae_se_apply(int dtype, const void* x, const void* skip, void* y, int B, int HW, int C,
                   const float* gate, float skip_scale, float branch_scale, void* stream);
 int nvae_se_bwd_reduce(int dtype, const void* x, const void* dy, int B, int HW, int C,
-                       float* r /*[B,C] zeroed*/, void* stream);
+                       float* r /*[B,C]*/, void* stream);
 int nvae_se_gate_bwd(const float* r, const float* pooled_sum, const float* gate, const float* hidden,
                      int B, int HW, int C, int Hd, const float* w1, const float* w2, float branch_scale,
-                     float* dw1, float* db1, float* dw2, float* db2, float* dpool, void* stream);
+                     float* dw1, float* db1, float* dw2, float* db2, float* dpool,
+                     float* scratch /*[B*(C+Hd)]*/, void* stream);
 int nvae_se_bwd_apply(int dtype, const void* dy, const float* gate, const float* dpool, void* dx,
                       void* dskip, int B, int HW, int C, float skip_scale, float branch_scale,
                       int acc_dx, int acc_dskip, void* stream);

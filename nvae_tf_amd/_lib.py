@@ -39,23 +39,25 @@ _G = C.POINTER(ConvGeom)
 # name -> argtypes (the trailing stream argument is appended automatically)
 _SIGS = {
     "nvae_conv_gemm": [_i, _G, _p, _p, _i, _p, _p, _p, _i],
-    "nvae_conv_wgrad": [_i, _G, _p, _p, _p, _i],
+    "nvae_conv_wgrad": [_i, _G, _p, _p, _p, _i, _p],
     "nvae_conv_direct": [_i, _G, _p, _p, _l, _l, _l, _i, _p, _p, _p, _i],
     "nvae_conv_direct_wgrad": [_i, _G, _p, _p, _p, _i, _p],
     "nvae_colsum": [_i, _p, _l, _i, _i, _p],
     "nvae_dwconv5": [_i, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i],
     "nvae_dwconv5_wgrad": [_i, _p, _p, _p, _p, _i, _i, _i, _i],
+    "nvae_reduce_splits": None,
     "nvae_bn_stats": [_i, _p, _l, _i, _p],
     "nvae_bn_finalize": [_p, _l, _i, _p, _p, _p, _p, _f, _f, _p, _p, _p, _p],
     "nvae_bn_eval_prepare": [_p, _p, _p, _p, _i, _f, _p, _p],
     "nvae_bn_apply": [_i, _p, _p, _l, _i, _p, _p, _i],
-    "nvae_bn_bwd_reduce": [_i, _p, _p, _l, _i, _p, _p, _p, _p, _i, _p, _p],
-    "nvae_bn_bwd_apply": [_i, _p, _p, _p, _l, _i, _p, _p, _p, _p, _i, _p, _p, _i],
+    "nvae_bn_bwd_reduce": [_i, _p, _p, _l, _i, _p, _p, _i, _p],
+    "nvae_bn_bwd_finalize": [_p, _l, _i, _p, _p, _p, _p, _p, _p],
+    "nvae_bn_bwd_apply": [_i, _p, _p, _p, _l, _i, _p, _p, _p, _i, _i],
     "nvae_se_pool": [_i, _p, _i, _i, _i, _p],
     "nvae_se_gate": [_p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p],
     "nvae_se_apply": [_i, _p, _p, _p, _i, _i, _i, _p, _f, _f],
     "nvae_se_bwd_reduce": [_i, _p, _p, _i, _i, _i, _p],
-    "nvae_se_gate_bwd": [_p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _f, _p, _p, _p, _p, _p],
+    "nvae_se_gate_bwd": [_p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _f, _p, _p, _p, _p, _p, _p],
     "nvae_se_bwd_apply": [_i, _p, _p, _p, _p, _p, _i, _i, _i, _f, _f, _i, _i],
     "nvae_unary_fwd": [_i, _i, _p, _p, _l, _f, _f],
     "nvae_unary_bwd": [_i, _i, _p, _p, _p, _l, _i],
@@ -93,7 +95,11 @@ def load():
     lib.nvae_last_error.restype = C.c_char_p
     lib.nvae_last_error.argtypes = []
     lib.nvae_abi_version.restype = C.c_int
+    lib.nvae_reduce_splits.restype = C.c_int
+    lib.nvae_reduce_splits.argtypes = [_l, _i]
     for name, sig in _SIGS.items():
+        if sig is None:
+            continue
         fn = getattr(lib, name)
         fn.restype = C.c_int
         fn.argtypes = [*sig, _p]

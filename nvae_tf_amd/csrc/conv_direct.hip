@@ -105,6 +105,150 @@ __global__ void k_conv_direct_wgrad(NvaeConvGeom g, const T* __restrict__ x, con
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// "Thin" weight gradients: the three shapes above have K*N of a few hundred to a few thousand and
+// M = B*H*W of 2k-131k, so the work is a skinny reduction over pixels.  One thread keeps KT x 8
+// accumulators: out[j][c..c+7] += a_j(m) * v(m)[c..c+7] with a 16-B vector operand v and scalar a_j.
+//   VARIANT 0 (stem, latent half of the combiner): v = dy[m, n..n+7], a_j = x[pix(m, tap_j), ci_j]
+//   VARIANT 1 (1-channel logit head):              v = x[pix(m, tap_j), c..c+7], a = dy[m, 0]
+// Lanes over 8-channel groups (coalesced), row-lanes over pixels, wave shuffles + one LDS hop, then
+// f32 atomics with at most `S` (<= 32) adders per address.
+// ---------------------------------------------------------------------------------------
+#define THIN_KT 10
+template <typename T, int VARIANT>
+__global__ __launch_bounds__(256) void k_conv_thin_wgrad(NvaeConvGeom g, const T* __restrict__ x,
+                                                         const T* __restrict__ dy, float* dw, int dw_ld,
+                                                         float* db, int J, int rows_per_block) {
+    const int CV = VARIANT == 0 ? g.Cout : g.Cin;           // vectorised channel count
+    const int TGS = CV >= 64 ? 8 : (CV > 16 ? (CV > 32 ? 8 : 4) : (CV > 8 ? 2 : 1));
+    const int RL = 256 / TGS;
+    const int tg = threadIdx.x % TGS, rl = threadIdx.x / TGS;
+    const int c0 = blockIdx.x * 64 + tg * 8;
+    const bool cval = c0 < CV;
+    const int j0 = blockIdx.z * THIN_KT;
+    const long M = (long)g.B * g.Hout * g.Wout;
+    const long r0 = (long)blockIdx.y * rows_per_block;
+    long r1 = r0 + rows_per_block;
+    if (r1 > M) r1 = M;
+    int jkh[THIN_KT], jkw[THIN_KT], jci[THIN_KT];
+#pragma unroll
+    for (int j = 0; j < THIN_KT; ++j) {
+        int jj = j0 + j;
+        int tap = VARIANT == 0 ? jj / g.Cin : jj;
+        jci[j] = VARIANT == 0 ? jj - tap * g.Cin : 0;
+        jkh[j] = tap / g.KW;
+        jkw[j] = tap - jkh[j] * g.KW;
+    }
+    float acc[THIN_KT][8];
+    float accb[8];
+#pragma unroll
+    for (int j = 0; j < THIN_KT; ++j)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[j][e] = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) accb[e] = 0.f;
+    const bool do_bias = db != nullptr && blockIdx.z == 0;
+    if (cval) {
+        for (long m = r0 + rl; m < r1; m += RL) {
+            int wo = (int)(m % g.Wout);
+            long q = m / g.Wout;
+            int ho = (int)(q % g.Hout);
+            long b = q / g.Hout;
+            if (VARIANT == 0) {
+                float v[8];
+                V8<T>::ld(dy + m * g.out_ld + c0, v);
+                if (do_bias) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) accb[e] += v[e];
+                }
+#pragma unroll
+                for (int j = 0; j < THIN_KT; ++j) {
+                    if (j0 + j >= J) continue;
+                    int hs, ws;
+                    if (!src_coord(ho, jkh[j], g.stride, g.pad_t, g.div, g.exact, g.Hin, hs)) continue;
+                    if (!src_coord(wo, jkw[j], g.stride, g.pad_l, g.div, g.exact, g.Win, ws)) continue;
+                    float a = ldf<T>(x + ((b * g.Hin + hs) * (long)g.Win + ws) * g.in_ld + jci[j]);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) acc[j][e] += a * v[e];
+                }
+            } else {
+                float a = ldf<T>(dy + m * g.out_ld);
+                if (do_bias && tg == 0 && blockIdx.x == 0) accb[0] += a;
+#pragma unroll
+                for (int j = 0; j < THIN_KT; ++j) {
+                    if (j0 + j >= J) continue;
+                    int hs, ws;
+                    if (!src_coord(ho, jkh[j], g.stride, g.pad_t, g.div, g.exact, g.Hin, hs)) continue;
+                    if (!src_coord(wo, jkw[j], g.stride, g.pad_l, g.div, g.exact, g.Win, ws)) continue;
+                    float v[8];
+                    V8<T>::ld(x + ((b * g.Hin + hs) * (long)g.Win + ws) * g.in_ld + c0, v);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) acc[j][e] += a * v[e];
+                }
+            }
+        }
+    }
+    // reduce over row lanes: shuffles inside the wave, then LDS across the 4 waves
+    __shared__ float sm[4][8][(THIN_KT + 1) * 8];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+    for (int j = 0; j <= THIN_KT; ++j)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float v = j < THIN_KT ? acc[j][e] : accb[e];
+            for (int o = 32; o >= TGS; o >>= 1) v += __shfl_xor(v, o, 64);
+            if (lane < TGS) sm[wave][lane][j * 8 + e] = v;
+        }
+    __syncthreads();
+    if (threadIdx.x < TGS && cval) {
+#pragma unroll
+        for (int j = 0; j <= THIN_KT; ++j)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float v = sm[0][tg][j * 8 + e] + sm[1][tg][j * 8 + e] + sm[2][tg][j * 8 + e] + sm[3][tg][j * 8 + e];
+                if (j == THIN_KT) {
+                    if (!do_bias) continue;
+                    if (VARIANT == 0) atomicAdd(db + c0 + e, v);
+                    else if (e == 0 && tg == 0 && blockIdx.x == 0) atomicAdd(db, v);
+                } else if (j0 + j < J) {
+                    if (VARIANT == 0) atomicAdd(dw + (long)(j0 + j) * dw_ld + c0 + e, v);
+                    else atomicAdd(dw + ((long)(j0 + j) * g.Cin + c0 + e) * dw_ld, v);
+                }
+            }
+    }
+}
+
+template <typename T>
+static bool launch_thin_wgrad(const NvaeConvGeom* g, const void* x, const void* dy, float* dw, int dw_ld,
+                              float* db, hipStream_t s) {
+    constexpr int ve = sizeof(T) == 2 ? 8 : 4;
+    const long M = (long)g->B * g->Hout * g->Wout;
+    int variant, J, CV;
+    if (g->Cout % 8 == 0 && g->out_ld % ve == 0 && aligned16(dy) && g->KH * g->KW * g->Cin <= 64) {
+        variant = 0; J = g->KH * g->KW * g->Cin; CV = g->Cout;
+    } else if (g->Cout == 1 && g->Cin % 8 == 0 && g->in_ld % ve == 0 && aligned16(x)) {
+        variant = 1; J = g->KH * g->KW; CV = g->Cin;
+    } else {
+        return false;
+    }
+    const int tgs = CV >= 64 ? 8 : (CV > 16 ? (CV > 32 ? 8 : 4) : (CV > 8 ? 2 : 1));
+    const int rl = 256 / tgs;
+    const int strips = (CV + 63) / 64, kch = (J + THIN_KT - 1) / THIN_KT;
+    long S = 512 / (strips * kch);
+    if (S > 32) S = 32;
+    long max_s = M / (rl * 2L);
+    if (S > max_s) S = max_s;
+    if (S < 1) S = 1;
+    long rpb = (M + S - 1) / S;
+    S = (M + rpb - 1) / rpb;
+    dim3 grid(strips, (unsigned)S, kch);
+    if (variant == 0)
+        hipLaunchKernelGGL((k_conv_thin_wgrad<T, 0>), grid, 256, 0, s, *g, (const T*)x, (const T*)dy, dw, dw_ld, db, J, (int)rpb);
+    else
+        hipLaunchKernelGGL((k_conv_thin_wgrad<T, 1>), grid, 256, 0, s, *g, (const T*)x, (const T*)dy, dw, dw_ld, db, J, (int)rpb);
+    return true;
+}
+
 extern "C" int nvae_conv_direct_wgrad(int dtype, const NvaeConvGeom* g, const void* x, const void* dy,
                                       float* dw, int dw_ld, float* db, void* stream) {
     if (int e = check_geom("conv_direct_wgrad", g)) return e;
@@ -112,6 +256,14 @@ extern "C" int nvae_conv_direct_wgrad(int dtype, const NvaeConvGeom* g, const vo
     int K = g->KH * g->KW * g->Cin;
     long blocks = (long)(K + (db ? 1 : 0)) * g->Cout;
     NVAE_REQUIRE(blocks < (1L << 31), "conv_direct_wgrad: too many weights");
+    {
+        bool done = false;
+        DISPATCH_T(dtype, done = launch_thin_wgrad<T>(g, x, dy, dw, dw_ld, db, (hipStream_t)stream);)
+        if (done) {
+            NVAE_LAUNCH_CHECK("conv_thin_wgrad");
+            return NVAE_OK;
+        }
+    }
     DISPATCH_T(dtype, hipLaunchKernelGGL((k_conv_direct_wgrad<T>), (int)blocks, 256, 0, (hipStream_t)stream, *g, (const T*)x, (const T*)dy, dw, dw_ld, db, K);)
     NVAE_LAUNCH_CHECK("conv_direct_wgrad");
     return NVAE_OK;

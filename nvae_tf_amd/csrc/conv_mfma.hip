@@ -260,8 +260,8 @@ __device__ __forceinline__ int img_off(int m, int cc) {
 template <typename T, int BNT>
 __global__ __launch_bounds__(256, 2) void k_conv_wgrad(NvaeConvGeom g, const T* __restrict__ x,
                                                        const T* __restrict__ dy, float* dw, int dw_ld,
-                                                       int M, int K, int n_tiles, int m_per_split,
-                                                       FastDiv fd_hw, FastDiv fd_w) {
+                                                       float* db, int M, int K, int n_tiles,
+                                                       int m_per_split, FastDiv fd_hw, FastDiv fd_w) {
     constexpr int BKT = 128;
     constexpr int VE = Tr<T>::VE;
     constexpr int RS = 4 * VE;                 // pixels per reduction step (32 bf16 / 16 f32)
@@ -296,6 +296,13 @@ __global__ __launch_bounds__(256, 2) void k_conv_wgrad(NvaeConvGeom g, const T* 
     const int ncol = n0 + b_cc * VE;
     const bool nval = ncol < N;
 
+    // bias gradient db[n] = sum_m dy[m, n]: folded into the k-tile-0 workgroups, which already
+    // stream every dy element of their n range through registers
+    const bool do_bias = (db != nullptr) && (kt == 0);
+    float bsum[VE];
+#pragma unroll
+    for (int j = 0; j < VE; ++j) bsum[j] = 0.f;
+
     uint4 ra[A_CH], rb[B_CH];
     auto load_step = [&](int mbase) {
 #pragma unroll
@@ -322,6 +329,17 @@ __global__ __launch_bounds__(256, 2) void k_conv_wgrad(NvaeConvGeom g, const T* 
             int m = mbase + b_row0 + i * (256 / CPR_B);
             rb[i] = make_uint4(0, 0, 0, 0);
             if (nval && m < m_end) rb[i] = *(const uint4*)(dy + (long)m * g.out_ld + ncol);
+            if (do_bias) {
+                if constexpr (sizeof(T) == 2) {
+                    bsum[0] += __uint_as_float(rb[i].x << 16); bsum[1] += __uint_as_float(rb[i].x & 0xffff0000u);
+                    bsum[2] += __uint_as_float(rb[i].y << 16); bsum[3] += __uint_as_float(rb[i].y & 0xffff0000u);
+                    bsum[4] += __uint_as_float(rb[i].z << 16); bsum[5] += __uint_as_float(rb[i].z & 0xffff0000u);
+                    bsum[6] += __uint_as_float(rb[i].w << 16); bsum[7] += __uint_as_float(rb[i].w & 0xffff0000u);
+                } else {
+                    bsum[0] += __uint_as_float(rb[i].x); bsum[1] += __uint_as_float(rb[i].y);
+                    bsum[2] += __uint_as_float(rb[i].z); bsum[3] += __uint_as_float(rb[i].w);
+                }
+            }
         }
     };
 
@@ -412,6 +430,20 @@ __global__ __launch_bounds__(256, 2) void k_conv_wgrad(NvaeConvGeom g, const T* 
     }
 
     // ---- epilogue: f32 atomics into the flat gradient buffer ------------------------------
+    if (do_bias) {
+        __syncthreads();
+        float* red = (float*)lds[0];                 // [256 / CPR_B rows][CPR_B][VE]
+#pragma unroll
+        for (int j = 0; j < VE; ++j) red[tid * VE + j] = bsum[j];
+        __syncthreads();
+        if (tid < CPR_B * VE) {
+            const int cc = tid / VE, j = tid - cc * VE;
+            float a = 0.f;
+            for (int r = 0; r < 256 / CPR_B; ++r) a += red[(r * CPR_B + cc) * VE + j];
+            const int n = n0 + cc * VE + j;
+            if (n < N) atomicAdd(db + n, a);
+        }
+    }
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
         const int n = n0 + wn * (BNT / 2) + j * 16 + fr;
@@ -428,7 +460,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_wgrad(NvaeConvGeom g, const T* 
 
 template <typename T>
 static int launch_conv_wgrad(const NvaeConvGeom* g, const void* x, const void* dy, float* dw, int dw_ld,
-                             hipStream_t s) {
+                             float* db, hipStream_t s) {
     constexpr int RS = 4 * Tr<T>::VE;
     const int M = g->B * g->Hout * g->Wout, K = g->KH * g->KW * g->Cin, N = g->Cout;
     FastDiv fd_hw = make_fastdiv((unsigned)(g->Hout * g->Wout)), fd_w = make_fastdiv((unsigned)g->Wout);
@@ -446,21 +478,21 @@ static int launch_conv_wgrad(const NvaeConvGeom* g, const void* x, const void* d
     nsplit = cdiv(M, mps);
     dim3 grid(tiles, nsplit);
     if (wide)
-        hipLaunchKernelGGL((k_conv_wgrad<T, 128>), grid, 256, 0, s, *g, (const T*)x, (const T*)dy, dw, dw_ld, M, K, nt, mps, fd_hw, fd_w);
+        hipLaunchKernelGGL((k_conv_wgrad<T, 128>), grid, 256, 0, s, *g, (const T*)x, (const T*)dy, dw, dw_ld, db, M, K, nt, mps, fd_hw, fd_w);
     else
-        hipLaunchKernelGGL((k_conv_wgrad<T, 64>), grid, 256, 0, s, *g, (const T*)x, (const T*)dy, dw, dw_ld, M, K, nt, mps, fd_hw, fd_w);
+        hipLaunchKernelGGL((k_conv_wgrad<T, 64>), grid, 256, 0, s, *g, (const T*)x, (const T*)dy, dw, dw_ld, db, M, K, nt, mps, fd_hw, fd_w);
     return 0;
 }
 
 extern "C" int nvae_conv_wgrad(int dtype, const NvaeConvGeom* g, const void* x, const void* dy, float* dw,
-                               int dw_ld, void* stream) {
+                               int dw_ld, float* db, void* stream) {
     if (int e = check_geom_mfma("conv_wgrad", g)) return e;
     NVAE_REQUIRE(x && dy && dw && dw_ld >= g->Cout, "conv_wgrad: bad args");
     const int ve = (dtype == NVAE_BF16) ? 8 : 4;
     NVAE_REQUIRE(g->Cin % ve == 0 && g->in_ld % ve == 0 && g->Cout % ve == 0 && g->out_ld % ve == 0,
                  "conv_wgrad: Cin=%d Cout=%d and their lds must be multiples of %d (use nvae_conv_direct_wgrad)", g->Cin, g->Cout, ve);
     NVAE_REQUIRE(aligned16(x) && aligned16(dy), "conv_wgrad: x/dy must be 16-B aligned");
-    DISPATCH_T(dtype, launch_conv_wgrad<T>(g, x, dy, dw, dw_ld, (hipStream_t)stream);)
+    DISPATCH_T(dtype, launch_conv_wgrad<T>(g, x, dy, dw, dw_ld, db, (hipStream_t)stream);)
     NVAE_LAUNCH_CHECK("conv_wgrad");
     return NVAE_OK;
 }

@@ -165,12 +165,10 @@ def conv2d(ctx: Ctx, x: Var, conv, *, stride: int = 1, up: int = 1, pad: Optiona
             dw = ptr(ps.grads) + (conv.w.off + c_off * cout) * 4
             db = (ptr(ps.grads) + conv.b.off * 4) if (bias and conv.b is not None) else None
             gw = _geom(B, H, W, cin, Ho, Wo, cout, k, k, stride, pad[0], pad[1], up, 0, Cx, Cy, Cy)
-            w_mfma = (cin % ve == 0 and Cx % ve == 0 and cout % 8 == 0 and Cy % ve == 0
+            w_mfma = (cin % ve == 0 and Cx % ve == 0 and cout % ve == 0 and Cy % ve == 0
                       and out_coff % ve == 0)
             if w_mfma:
-                call("nvae_conv_wgrad", ctx.dt, C.byref(gw), ptr(x.t), dy_ptr, dw, cout)
-                if db is not None:
-                    call("nvae_colsum", ctx.dt, dy_ptr, B * Ho * Wo, cout, Cy, db)
+                call("nvae_conv_wgrad", ctx.dt, C.byref(gw), ptr(x.t), dy_ptr, dw, cout, db)
             else:
                 call("nvae_conv_direct_wgrad", ctx.dt, C.byref(gw), ptr(x.t), dy_ptr, dw, cout, db)
             # ---- residual
@@ -236,10 +234,11 @@ def bn_act(ctx: Ctx, x: Var, bn, act: int = L.ACT_NONE) -> Var:
     scale, shift, mean, invstd = (ptr(coef) + i * Cc * 4 for i in range(4))
     gamma, beta = ptr(ps.view(bn.gamma)), ptr(ps.view(bn.beta))
     rm, rv = ptr(ps.sview(bn.rm)), ptr(ps.sview(bn.rv))
+    S = L.load().nvae_reduce_splits(rows, Cc)
     if ctx.training:
-        sums = ctx.zeros_f32(2 * Cc)
-        call("nvae_bn_stats", ctx.dt, ptr(x.t), rows, Cc, ptr(sums))
-        call("nvae_bn_finalize", ptr(sums), rows, Cc, gamma, beta, rm, rv, BN_MOMENTUM, BN_EPS, scale,
+        partials = ctx.empty((S, 2, Cc), torch.float32)
+        call("nvae_bn_stats", ctx.dt, ptr(x.t), rows, Cc, ptr(partials))
+        call("nvae_bn_finalize", ptr(partials), rows, Cc, gamma, beta, rm, rv, BN_MOMENTUM, BN_EPS, scale,
              shift, mean, invstd)
     else:
         call("nvae_bn_eval_prepare", gamma, beta, rm, rv, Cc, BN_EPS, scale, shift)
@@ -251,12 +250,14 @@ def bn_act(ctx: Ctx, x: Var, bn, act: int = L.ACT_NONE) -> Var:
         def bwd():
             dgamma = ptr(ps.grads) + bn.gamma.off * 4
             dbeta = ptr(ps.grads) + bn.beta.off * 4
-            call("nvae_bn_bwd_reduce", ctx.dt, ptr(x.t), ptr(y.g), rows, Cc, scale, shift, mean, invstd,
-                 act, dgamma, dbeta)
+            part = ctx.empty((S, 2, Cc), torch.float32)
+            k0k1 = ctx.empty((2, Cc), torch.float32)
+            call("nvae_bn_bwd_reduce", ctx.dt, ptr(x.t), ptr(y.g), rows, Cc, scale, shift, act, ptr(part))
+            call("nvae_bn_bwd_finalize", ptr(part), rows, Cc, scale, mean, invstd, dgamma, dbeta, ptr(k0k1))
             if x.needs_grad:
                 g, acc = ctx.grad_of(x)
-                call("nvae_bn_bwd_apply", ctx.dt, ptr(x.t), ptr(y.g), ptr(g), rows, Cc, scale, shift, mean,
-                     invstd, act, dgamma, dbeta, acc)
+                call("nvae_bn_bwd_apply", ctx.dt, ptr(x.t), ptr(y.g), ptr(g), rows, Cc, scale, shift,
+                     ptr(k0k1), act, acc)
             _ = coef   # keep alive
         ctx.tape.append(bwd)
     return y
@@ -270,7 +271,7 @@ def se_residual(ctx: Ctx, x: Var, se, skip: Var, skip_scale: float, branch_scale
     ps = ctx.ps
     B, H, W, Cc = x.t.shape
     HW, Hd = H * W, se.hidden
-    pooled = ctx.zeros_f32(B * Cc) if True else None
+    pooled = ctx.empty((B, Cc), torch.float32)
     gate = ctx.empty((B, Cc), torch.float32)
     hidden = ctx.empty((B, Hd), torch.float32)
     w1, b1, w2, b2 = (ptr(ps.view(p)) for p in (se.w1, se.b1, se.w2, se.b2))
@@ -280,15 +281,15 @@ def se_residual(ctx: Ctx, x: Var, se, skip: Var, skip_scale: float, branch_scale
     call("nvae_se_apply", ctx.dt, ptr(x.t), ptr(skip.t), ptr(y.t), B, HW, Cc, ptr(gate), skip_scale,
          branch_scale)
     if ctx.record:
-        r = ctx.zeros_f32(B * Cc)
-
         def bwd():
+            r = ctx.empty((B, Cc), torch.float32)
             dpool = ctx.empty((B, Cc), torch.float32)
+            scratch = ctx.empty((B, Cc + Hd), torch.float32)
             call("nvae_se_bwd_reduce", ctx.dt, ptr(x.t), ptr(y.g), B, HW, Cc, ptr(r))
             gp = ptr(ps.grads)
             call("nvae_se_gate_bwd", ptr(r), ptr(pooled), ptr(gate), ptr(hidden), B, HW, Cc, Hd, w1, w2,
                  branch_scale, gp + se.w1.off * 4, gp + se.b1.off * 4, gp + se.w2.off * 4,
-                 gp + se.b2.off * 4, ptr(dpool))
+                 gp + se.b2.off * 4, ptr(dpool), ptr(scratch))
             gx, accx = ctx.grad_of(x)
             if skip.needs_grad:
                 gs, accs = ctx.grad_of(skip)

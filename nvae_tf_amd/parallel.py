@@ -1,0 +1,77 @@
+"""Data parallelism: one process per GPU, `torch.distributed` (backend "nccl" = RCCL over xGMI).
+
+The path shards by samples: every rank holds a full replica and its own slice of the
+global batch; the only exchange steps are (i) the [G]-float KL-balance statistic and (ii) the
+gradient all-reduce.  Gradients live in ONE flat f32 buffer (params.ParamStore), so the reducer
+works on contiguous bucket views, issued from the END of the buffer first: the flat layout is
+construction order (pre, enc, dec, post) and backward produces gradients in the reverse order.
+The reducer is backend-agnostic (gloo on CPU tensors in the unit tests)."""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import torch
+import torch.distributed as dist
+
+
+class GradReducer:
+    def __init__(self, group: Optional[dist.ProcessGroup] = None, bucket_bytes: int = 64 << 20):
+        assert dist.is_initialized()
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.bucket_elems = max(bucket_bytes // 4, 1)
+        backend = dist.get_backend(group)
+        self.native_avg = backend == "nccl"   # RCCL supports ReduceOp.AVG; gloo does not
+
+    def buckets(self, n: int) -> List[slice]:
+        """Contiguous slices covering [0, n), last-produced gradients (end of buffer) first."""
+        out, hi = [], n
+        while hi > 0:
+            lo = max(hi - self.bucket_elems, 0)
+            out.append(slice(lo, hi))
+            hi = lo
+        return out
+
+    def _allreduce_mean(self, t: torch.Tensor, async_op: bool):
+        if self.native_avg:
+            return dist.all_reduce(t, op=dist.ReduceOp.AVG, group=self.group, async_op=async_op), False
+        return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op), True
+
+    def allreduce_mean_(self, t: torch.Tensor) -> torch.Tensor:
+        if self.world == 1:
+            return t
+        _, need_div = self._allreduce_mean(t, False)
+        if need_div:
+            t.div_(self.world)
+        return t
+
+    def allreduce_grads_(self, flat: torch.Tensor) -> torch.Tensor:
+        """Average the flat gradient buffer across ranks, bucket by bucket (all in flight at once)."""
+        if self.world == 1:
+            return flat
+        works, need_div = [], False
+        for s in self.buckets(flat.numel()):
+            w, nd = self._allreduce_mean(flat[s], True)
+            works.append(w)
+            need_div = need_div or nd
+        for w in works:
+            w.wait()
+        if need_div:
+            flat.div_(self.world)
+        return flat
+
+
+def init_from_env(device_index: Optional[int] = None):
+    """Initialise torch.distributed from torchrun's environment.  Returns (rank, world, local_rank)."""
+    import os
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local if device_index is None else device_index)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
