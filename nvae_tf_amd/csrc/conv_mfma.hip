@@ -182,6 +182,178 @@ __global__ __launch_bounds__(256, 2) void k_conv_gemm(NvaeConvGeom g, const T* _
     }
 }
 
+// =========================================================================================
+// k_conv_gemm2: the same implicit GEMM with the staging done by LDS-DMA (global_load_lds_dwordx4,
+// no staging registers, no ds_write) into a 3-deep LDS ring, BK = 8 chunks (64 bf16 / 32 f32) per
+// barrier.  The DMA is issued through inline asm so that hipcc does not know about the pending LDS
+// writes (it would otherwise put s_waitcnt vmcnt(0) in front of every ds_read); completion is
+// tracked by hand: one counted s_waitcnt vmcnt(NLOAD) + one raw s_barrier per K-step, with the loads
+// of step t+2 issued right after the barrier of step t (ring slot (t+2)%3 was last read in step t-1,
+// which every wave has finished once it passed that barrier).
+//   LDS image per stage: [BM + BN rows][8 slots of 16 B]; slot = chunk ^ ((row >> 1) & 7): lane-linear
+//   for the DMA (the swizzle is applied to the per-lane SOURCE address) and conflict-free for the
+//   16x16x32 operand reads (checked against the ds_read_b128 16-lane groups).
+//   Out-of-image (padding) and out-of-range lanes read a 16-B zero buffer instead of being masked:
+//   LDS-DMA needs every lane to write its slot.
+// =========================================================================================
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+template <int N> __device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <typename T, int BM, int BN, int WM, int WN, int STAGES>
+__global__ __launch_bounds__(WM* WN * 64) void k_conv_gemm2(
+    NvaeConvGeom g, const T* __restrict__ src, const T* __restrict__ wT, int w_ld,
+    const float* __restrict__ bias, const T* residual, void* out, int out_f32, int M, int K, int n_tiles,
+    int total_tiles, FastDiv fd_hw, FastDiv fd_w, const uint4* __restrict__ zeros) {
+    constexpr int NT = WM * WN * 64;
+    constexpr int VE = Tr<T>::VE;
+    constexpr int BKE = 8 * VE;
+    constexpr int ACH = BM * 8 / NT, BCH = BN * 8 / NT;
+    constexpr int MI = BM / WM / 16, NI = BN / WN / 16;
+    constexpr int STAGE = (BM + BN) * 8;           // uint4 per ring slot
+    constexpr int NLOAD = ACH + BCH;
+    static_assert(ACH >= 1 && BCH >= 1 && (NT / 8) % 16 == 0, "tile/thread mismatch");
+    static_assert(STAGES == 2 || STAGES == 3, "ring depth");
+    __shared__ uint4 lds[STAGES * STAGE];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave - wm * WN;
+    const int tile = xcd_remap(blockIdx.x, total_tiles);
+    const int bm = tile / n_tiles, bn = tile - bm * n_tiles;
+    const int N = g.Cout;
+    const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)lds;
+
+    // ---- per-thread gather state: chunk q = tid + NT*i  ->  row q>>3, physical slot q&7
+    const int row0 = tid >> 3;
+    const int kc = ((tid & 7) ^ ((row0 >> 1) & 7)) * VE;
+    int tap = kc / g.Cin;
+    int ci = kc - tap * g.Cin;
+    int kh = tap / g.KW, kw = tap - kh * g.KW;
+    int kabs = kc;
+    const int hlim = g.Hin * g.div, wlim = g.Win * g.div;
+
+    int hb[ACH], wb[ACH];
+    long pb[ACH];
+    bool mv[ACH];
+#pragma unroll
+    for (int i = 0; i < ACH; ++i) {
+        int m = bm * BM + row0 + (NT / 8) * i;
+        mv[i] = m < M;
+        unsigned mm = mv[i] ? (unsigned)m : 0u;
+        unsigned b = fdiv(mm, fd_hw);
+        unsigned rem = mm - b * fd_hw.d;
+        unsigned ho = fdiv(rem, fd_w);
+        unsigned wo = rem - ho * fd_w.d;
+        hb[i] = (int)ho * g.stride - g.pad_t;
+        wb[i] = (int)wo * g.stride - g.pad_l;
+        pb[i] = (long)b * g.Hin * g.Win;
+    }
+    const T* bp[BCH];
+    bool nv[BCH];
+#pragma unroll
+    for (int j = 0; j < BCH; ++j) {
+        int n = bn * BN + row0 + (NT / 8) * j;
+        nv[j] = n < N;
+        bp[j] = wT + (long)(nv[j] ? n : 0) * w_ld;
+    }
+
+    auto issue = [&](int slot) {
+        const bool kval = kabs < K;
+        const unsigned dst = lds_base + (unsigned)(slot * STAGE + wave * 64) * 16u;
+#pragma unroll
+        for (int i = 0; i < ACH; ++i) {
+            int hc = hb[i] + kh, wc = wb[i] + kw;
+            bool ok = mv[i] && kval && hc >= 0 && hc < hlim && wc >= 0 && wc < wlim;
+            int hs = hc, ws = wc;
+            if (g.div != 1) {
+                hs = hc / g.div; ws = wc / g.div;
+                if (g.exact) ok = ok && (hs * g.div == hc) && (ws * g.div == wc);
+            }
+            const void* p = ok ? (const void*)(src + (pb[i] + (long)hs * g.Win + ws) * g.in_ld + ci) : (const void*)zeros;
+            glds16(p, dst + (unsigned)(NT * i) * 16u);
+        }
+#pragma unroll
+        for (int j = 0; j < BCH; ++j) {
+            const void* p = (nv[j] && kval) ? (const void*)(bp[j] + kabs) : (const void*)zeros;
+            glds16(p, dst + (unsigned)(BM * 8 + NT * j) * 16u);
+        }
+        kabs += BKE;
+        ci += BKE;
+        while (ci >= g.Cin) {
+            ci -= g.Cin;
+            if (++kw == g.KW) { kw = 0; ++kh; }
+        }
+    };
+
+    f32x4 acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int nk = (K + BKE - 1) / BKE;
+    const int fr = lane & 15, fq = lane >> 4;
+    issue(0);
+    if (STAGES == 3 && nk > 1) issue(1);
+    int cur = 0;
+    for (int t = 0; t < nk; ++t) {
+        if (STAGES == 3 && t + 1 < nk) wait_vmcnt<NLOAD>();
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        // refill the slot that was read in step t-1 with the tile of step t + STAGES - 1
+        if (t + STAGES - 1 < nk) issue(cur >= 1 ? cur - 1 : STAGES - 1);
+        const uint4* buf = lds + cur * STAGE;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            uint4 af[MI], bf[NI];
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                int r = wm * (BM / WM) + i * 16 + fr;
+                af[i] = buf[r * 8 + ((h * 4 + fq) ^ ((r >> 1) & 7))];
+            }
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+                int r = wn * (BN / WN) + j * 16 + fr;
+                bf[j] = buf[BM * 8 + r * 8 + ((h * 4 + fq) ^ ((r >> 1) & 7))];
+            }
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j) mfma_step<T>(af[i], bf[j], acc[i][j]);
+        }
+        cur = cur == STAGES - 1 ? 0 : cur + 1;
+    }
+
+    // ---- epilogue: bias + residual, direct stores ---------------------------------------
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+        const int n = bn * BN + wn * (BN / WN) + j * 16 + fr;
+        if (n >= N) continue;
+        const float bv = bias ? bias[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = bm * BM + wm * (BM / WM) + i * 16 + fq * 4 + r;
+                if (m >= M) continue;
+                float v = acc[i][j][r] + bv;
+                if (residual) v += ldf<T>(residual + (long)m * g.res_ld + n);
+                if (out_f32) ((float*)out)[(long)m * g.out_ld + n] = v;
+                else stf<T>((T*)out + (long)m * g.out_ld + n, v);
+            }
+        }
+    }
+}
+
+__device__ uint4 g_zero16[1];   // zero page for padded / out-of-range DMA lanes (zero-initialised)
+
 static int check_geom_mfma(const char* who, const NvaeConvGeom* g) {
     NVAE_REQUIRE(g, "%s: NULL geometry", who);
     NVAE_REQUIRE(g->B > 0 && g->Hin > 0 && g->Win > 0 && g->Cin > 0 && g->Hout > 0 && g->Wout > 0 && g->Cout > 0,
@@ -200,25 +372,30 @@ static int launch_conv_gemm(const NvaeConvGeom* g, const void* src, const void* 
                             hipStream_t s) {
     const int M = g->B * g->Hout * g->Wout, K = g->KH * g->KW * g->Cin, N = g->Cout;
     FastDiv fd_hw = make_fastdiv((unsigned)(g->Hout * g->Wout)), fd_w = make_fastdiv((unsigned)g->Wout);
-    const int mt = cdiv(M, 128);
-#define LAUNCH_BN(BN_)                                                                              \
-    {                                                                                               \
-        int nt = cdiv(N, BN_);                                                                      \
-        hipLaunchKernelGGL((k_conv_gemm<T, BN_>), mt * nt, 256, 0, s, *g, (const T*)src, (const T*)wT, \
-                           w_ld, bias, (const T*)residual, out, out_f32, M, K, nt, mt * nt, fd_hw, fd_w); \
+    uint4* zeros = nullptr;
+    (void)hipGetSymbolAddress((void**)&zeros, HIP_SYMBOL(g_zero16));
+#define LAUNCH2(BM_, BN_, WM_, WN_, ST_)                                                                \
+    {                                                                                                   \
+        int mt = cdiv(M, BM_), nt = cdiv(N, BN_);                                                       \
+        hipLaunchKernelGGL((k_conv_gemm2<T, BM_, BN_, WM_, WN_, ST_>), mt * nt, WM_ * WN_ * 64, 0, s, *g, \
+                           (const T*)src, (const T*)wT, w_ld, bias, (const T*)residual, out, out_f32, M, \
+                           K, nt, mt * nt, fd_hw, fd_w, zeros);                                         \
     }
-    // pick the N tile with the least padding waste; prefer the larger on ties
-    int best = 64;
-    long waste_best = (long)cdiv(N, 64) * 64;
-    const int cands[2] = {128, 192};
-    for (int c = 0; c < 2; ++c) {
-        long w = (long)cdiv(N, cands[c]) * cands[c];
-        if (w <= waste_best) { waste_best = w; best = cands[c]; }
+    // Large problems: 128-row tiles, 8 waves; N tile with the least padding (ties -> larger).
+    // Small problems (few tiles): 64 x 64 tiles, 4 waves, so that the grid covers the chip.
+    const long big_tiles = (long)cdiv(M, 128) * cdiv(N, 128);
+    const long w192 = (long)cdiv(N, 192) * 192, w128 = (long)cdiv(N, 128) * 128, w64 = (long)cdiv(N, 64) * 64;
+    if ((long)cdiv(M, 256) * cdiv(N, 192) >= 224 && w192 <= w128 && w192 <= w64 && K >= 1024) {
+        // the FLOP-dominant layers: 256 x 192 tile (112 FLOP per staged byte), 2-deep ring (112 KB)
+        LAUNCH2(256, 192, 4, 2, 2)
+    } else if (big_tiles >= 192) {
+        if (w192 <= w128 && w192 <= w64) LAUNCH2(128, 192, 2, 4, 3)
+        else if (w128 <= w64) LAUNCH2(128, 128, 2, 4, 3)
+        else LAUNCH2(128, 64, 4, 2, 3)
+    } else {
+        LAUNCH2(64, 64, 2, 2, 3)
     }
-    if (best == 192) LAUNCH_BN(192)
-    else if (best == 128) LAUNCH_BN(128)
-    else LAUNCH_BN(64)
-#undef LAUNCH_BN
+#undef LAUNCH2
     return 0;
 }
 
