@@ -635,29 +635,253 @@ __global__ __launch_bounds__(256, 2) void k_conv_wgrad(NvaeConvGeom g, const T* 
     }
 }
 
+// =========================================================================================
+// k_conv_wgrad2: weight gradient with the LDS-DMA ring.  Per ring step RS = 8 chunks-worth of pixels
+// (64 bf16 / 32 f32) of the pixel-major x-gather [RS][KT] and dy [RS][NTL] images are DMA'd into LDS;
+// the images keep the XOR-swizzled 32-B segment layout of k_conv_wgrad (transposing ds_read_b64_tr_b16
+// fragment reads), with the swizzle moved to the DMA's per-lane source address.
+// =========================================================================================
+template <typename T, int COLS>
+__device__ __forceinline__ int img_src_chunk(int m, int pc) {
+    // inverse of img_off: which logical 16-B chunk lands at physical chunk `pc` of pixel row `m`
+    if constexpr (sizeof(T) == 2) {
+        int s = (COLS >= 128) ? ((m & 3) | (((m >> 3) & 1) << 2)) : (((m >> 1) & 1) | (((m >> 3) & 1) << 1));
+        return (((pc >> 1) ^ s) << 1) | (pc & 1);
+    } else {
+        return (((pc >> 2) ^ (m & 1)) << 2) | (pc & 3);
+    }
+}
+
+template <typename T, int KT, int NTL, int WK, int WN, int STAGES>
+__global__ __launch_bounds__(WK* WN * 64) void k_conv_wgrad2(
+    NvaeConvGeom g, const T* __restrict__ x, const T* __restrict__ dy, float* dw, int dw_ld, float* db,
+    int M, int K, int n_tiles, int m_per_split, FastDiv fd_hw, FastDiv fd_w,
+    const uint4* __restrict__ zeros) {
+    constexpr int NT = WK * WN * 64;
+    constexpr int VE = Tr<T>::VE;
+    constexpr int RS = 8 * VE;                      // pixels per ring step
+    constexpr int CPR_A = KT / VE, CPR_B = NTL / VE;
+    constexpr int ACH = RS * CPR_A / NT, BCH = RS * CPR_B / NT;
+    constexpr int MI = KT / WK / 16, NI = NTL / WN / 16;
+    constexpr int A_BYTES = RS * KT * (int)sizeof(T), B_BYTES = RS * NTL * (int)sizeof(T);
+    constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
+    constexpr int NLOAD = ACH + BCH;
+    static_assert(ACH >= 1 && BCH >= 1, "tile/thread mismatch");
+    static_assert((NT / CPR_A) % 16 == 0 || sizeof(T) == 4, "A rows per pass must keep the swizzle invariant");
+    static_assert((NT / CPR_B) % 16 == 0 || sizeof(T) == 4, "B rows per pass must keep the swizzle invariant");
+    static_assert((NT / CPR_A) % 2 == 0 && (NT / CPR_B) % 2 == 0, "row step parity");
+    __shared__ __attribute__((aligned(16))) unsigned char lds[STAGES * STAGE_BYTES];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wk = wave / WN, wn = wave - wk * WN;
+    const int kt = blockIdx.x / n_tiles, nt = blockIdx.x - kt * n_tiles;
+    const int k0 = kt * KT, n0 = nt * NTL;
+    const int N = g.Cout;
+    const int m_begin = blockIdx.y * m_per_split;
+    int m_end = m_begin + m_per_split;
+    if (m_end > M) m_end = M;
+    const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)lds;
+
+    // A side: physical chunk (a_row0 + pass*rows, a_pc); logical k column fixed per thread
+    const int a_pc = tid % CPR_A, a_row0 = tid / CPR_A;
+    const int kcol = k0 + img_src_chunk<T, KT>(a_row0, a_pc) * VE;
+    const bool kval = kcol < K;
+    const int tap = kval ? kcol / g.Cin : 0;
+    const int ci = kval ? kcol - tap * g.Cin : 0;
+    const int kh = tap / g.KW, kw = tap - kh * g.KW;
+    const int hlim = g.Hin * g.div, wlim = g.Win * g.div;
+    const int b_pc = tid % CPR_B, b_row0 = tid / CPR_B;
+    const int ncol = n0 + img_src_chunk<T, NTL>(b_row0, b_pc) * VE;
+    const bool nval = ncol < N;
+
+    auto issue = [&](int slot, int mbase) {
+        const unsigned dst = lds_base + (unsigned)(slot * STAGE_BYTES) + (unsigned)(wave * 64) * 16u;
+#pragma unroll
+        for (int i = 0; i < ACH; ++i) {
+            const int m = mbase + a_row0 + i * (NT / CPR_A);
+            const void* p = zeros;
+            if (kval && m < m_end) {
+                unsigned b = fdiv((unsigned)m, fd_hw);
+                unsigned rem = (unsigned)m - b * fd_hw.d;
+                unsigned ho = fdiv(rem, fd_w);
+                unsigned wo = rem - ho * fd_w.d;
+                int hc = (int)ho * g.stride - g.pad_t + kh, wc = (int)wo * g.stride - g.pad_l + kw;
+                bool ok = hc >= 0 && hc < hlim && wc >= 0 && wc < wlim;
+                int hs = hc, ws = wc;
+                if (g.div != 1) {
+                    hs = hc / g.div; ws = wc / g.div;
+                    if (g.exact) ok = ok && (hs * g.div == hc) && (ws * g.div == wc);
+                }
+                if (ok) p = x + ((long)b * g.Hin * g.Win + (long)hs * g.Win + ws) * g.in_ld + ci;
+            }
+            glds16(p, dst + (unsigned)(NT * i) * 16u);
+        }
+#pragma unroll
+        for (int j = 0; j < BCH; ++j) {
+            const int m = mbase + b_row0 + j * (NT / CPR_B);
+            const void* p = (nval && m < m_end) ? (const void*)(dy + (long)m * g.out_ld + ncol) : (const void*)zeros;
+            glds16(p, dst + (unsigned)A_BYTES + (unsigned)(NT * j) * 16u);
+        }
+    };
+
+    f32x4 acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const bool do_bias = (db != nullptr) && (kt == 0);
+    float bsum[VE];
+#pragma unroll
+    for (int j = 0; j < VE; ++j) bsum[j] = 0.f;
+
+    const int fr = lane & 15, fq = lane >> 4;
+    const int nsteps = (m_end - m_begin + RS - 1) / RS;
+    if (nsteps > 0) issue(0, m_begin);
+    if (STAGES == 3 && nsteps > 1) issue(1, m_begin + RS);
+    int cur = 0;
+    for (int t = 0; t < nsteps; ++t) {
+        if (STAGES == 3 && t + 1 < nsteps) wait_vmcnt<NLOAD>();
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (t + STAGES - 1 < nsteps) issue(cur >= 1 ? cur - 1 : STAGES - 1, m_begin + (t + STAGES - 1) * RS);
+        const unsigned char* bufA = lds + cur * STAGE_BYTES;
+        const unsigned char* bufB = bufA + A_BYTES;
+        if (do_bias) {
+            // re-read this thread's own DMA'd dy chunks (fixed column, RS/(NT/CPR_B) rows)
+#pragma unroll
+            for (int j = 0; j < BCH; ++j) {
+                uint4 v = *(const uint4*)(bufB + (tid + NT * j) * 16);
+                if constexpr (sizeof(T) == 2) {
+                    bsum[0] += __uint_as_float(v.x << 16); bsum[1] += __uint_as_float(v.x & 0xffff0000u);
+                    bsum[2] += __uint_as_float(v.y << 16); bsum[3] += __uint_as_float(v.y & 0xffff0000u);
+                    bsum[4] += __uint_as_float(v.z << 16); bsum[5] += __uint_as_float(v.z & 0xffff0000u);
+                    bsum[6] += __uint_as_float(v.w << 16); bsum[7] += __uint_as_float(v.w & 0xffff0000u);
+                } else {
+                    bsum[0] += __uint_as_float(v.x); bsum[1] += __uint_as_float(v.y);
+                    bsum[2] += __uint_as_float(v.z); bsum[3] += __uint_as_float(v.w);
+                }
+            }
+        }
+        if constexpr (sizeof(T) == 2) {
+            const int q = fr >> 2, p = fr & 3;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const int mr = ks * 32 + 8 * fq + q, mr1 = mr + 4;
+                const int s8_0 = (mr & 3) | (((mr >> 3) & 1) << 2), s8_1 = (mr1 & 3) | (((mr1 >> 3) & 1) << 2);
+                const int s4_0 = ((mr >> 1) & 1) | (((mr >> 3) & 1) << 1), s4_1 = ((mr1 >> 1) & 1) | (((mr1 >> 3) & 1) << 1);
+                const int sa0 = KT >= 128 ? s8_0 : s4_0, sa1 = KT >= 128 ? s8_1 : s4_1;
+                const int sb0 = NTL >= 128 ? s8_0 : s4_0, sb1 = NTL >= 128 ? s8_1 : s4_1;
+                bf16x8 af[MI], bfr[NI];
+#pragma unroll
+                for (int i = 0; i < MI; ++i) {
+                    const int seg = wk * (KT / WK / 16) + i;
+                    auto lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                        (__attribute__((address_space(3))) bf16x4*)(bufA + mr * (KT * 2) + ((seg ^ sa0) << 5) + p * 8));
+                    auto hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                        (__attribute__((address_space(3))) bf16x4*)(bufA + mr1 * (KT * 2) + ((seg ^ sa1) << 5) + p * 8));
+                    af[i] = (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                }
+#pragma unroll
+                for (int j = 0; j < NI; ++j) {
+                    const int seg = wn * (NTL / WN / 16) + j;
+                    auto lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                        (__attribute__((address_space(3))) bf16x4*)(bufB + mr * (NTL * 2) + ((seg ^ sb0) << 5) + p * 8));
+                    auto hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                        (__attribute__((address_space(3))) bf16x4*)(bufB + mr1 * (NTL * 2) + ((seg ^ sb1) << 5) + p * 8));
+                    bfr[j] = (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                }
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NI; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int sI = 0; sI < RS / 4; ++sI) {
+                const int m = 4 * sI + fq;
+                float af[MI], bfr[NI];
+#pragma unroll
+                for (int i = 0; i < MI; ++i) {
+                    int col = wk * (KT / WK) + i * 16 + fr;
+                    af[i] = *(const float*)(bufA + m * (KT * 4) + (((col >> 4) ^ (m & 1)) << 6) + ((col & 15) << 2));
+                }
+#pragma unroll
+                for (int j = 0; j < NI; ++j) {
+                    int col = wn * (NTL / WN) + j * 16 + fr;
+                    bfr[j] = *(const float*)(bufB + m * (NTL * 4) + (((col >> 4) ^ (m & 1)) << 6) + ((col & 15) << 2));
+                }
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NI; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bfr[j], acc[i][j], 0, 0, 0);
+            }
+        }
+        cur = cur == STAGES - 1 ? 0 : cur + 1;
+    }
+
+    if (do_bias) {
+        __syncthreads();
+        float* red = (float*)lds;                    // [NT / CPR_B rows][CPR_B][VE]
+#pragma unroll
+        for (int j = 0; j < VE; ++j) red[tid * VE + j] = bsum[j];
+        __syncthreads();
+        if (tid < CPR_B * VE) {
+            const int pc = tid / VE, j = tid - pc * VE;
+            // rows r hold physical chunk pc; their logical column depends on the row's swizzle
+            for (int r = 0; r < NT / CPR_B; ++r) {
+                const int n = n0 + img_src_chunk<T, NTL>(r, pc) * VE + j;
+                float a = red[(r * CPR_B + pc) * VE + j];
+                if (n < N && a != 0.f) atomicAdd(db + n, a);
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+        const int n = n0 + wn * (NTL / WN) + j * 16 + fr;
+        if (n >= N) continue;
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int k = k0 + wk * (KT / WK) + i * 16 + fq * 4 + r;
+                if (k < K) atomicAdd(dw + (long)k * dw_ld + n, acc[i][j][r]);
+            }
+    }
+}
+
 template <typename T>
 static int launch_conv_wgrad(const NvaeConvGeom* g, const void* x, const void* dy, float* dw, int dw_ld,
                              float* db, hipStream_t s) {
-    constexpr int RS = 4 * Tr<T>::VE;
+    constexpr int RS = 8 * Tr<T>::VE;
     const int M = g->B * g->Hout * g->Wout, K = g->KH * g->KW * g->Cin, N = g->Cout;
     FastDiv fd_hw = make_fastdiv((unsigned)(g->Hout * g->Wout)), fd_w = make_fastdiv((unsigned)g->Wout);
-    const int kt = cdiv(K, 128);
-    const bool wide = ((long)cdiv(N, 128) * 128 <= (long)cdiv(N, 64) * 64);
-    const int nt = wide ? cdiv(N, 128) : cdiv(N, 64);
-    const int tiles = kt * nt;
-    // split the pixel reduction so that the grid holds ~1024 workgroups, >= 8 steps per split
-    int nsplit = 1024 / tiles;
-    int max_split = M / (RS * 8);
-    if (nsplit > max_split) nsplit = max_split;
-    if (nsplit < 1) nsplit = 1;
-    int mps = cdiv(M, nsplit);
-    mps = ((mps + RS - 1) / RS) * RS;
-    nsplit = cdiv(M, mps);
-    dim3 grid(tiles, nsplit);
-    if (wide)
-        hipLaunchKernelGGL((k_conv_wgrad<T, 128>), grid, 256, 0, s, *g, (const T*)x, (const T*)dy, dw, dw_ld, db, M, K, nt, mps, fd_hw, fd_w);
-    else
-        hipLaunchKernelGGL((k_conv_wgrad<T, 64>), grid, 256, 0, s, *g, (const T*)x, (const T*)dy, dw, dw_ld, db, M, K, nt, mps, fd_hw, fd_w);
+    uint4* zeros = nullptr;
+    (void)hipGetSymbolAddress((void**)&zeros, HIP_SYMBOL(g_zero16));
+#define LAUNCHW(KT_, NTL_, WK_, WN_, ST_, TARGET_)                                                      \
+    {                                                                                                   \
+        const int kt = cdiv(K, KT_), nt = cdiv(N, NTL_), tiles = kt * nt;                               \
+        int nsplit = (TARGET_) / tiles;                                                                 \
+        int max_split = M / (RS * 4);                                                                   \
+        if (nsplit > max_split) nsplit = max_split;                                                     \
+        if (nsplit < 1) nsplit = 1;                                                                     \
+        int mps = cdiv(M, nsplit);                                                                      \
+        mps = ((mps + RS - 1) / RS) * RS;                                                               \
+        nsplit = cdiv(M, mps);                                                                          \
+        dim3 grid(tiles, nsplit);                                                                       \
+        hipLaunchKernelGGL((k_conv_wgrad2<T, KT_, NTL_, WK_, WN_, ST_>), grid, WK_ * WN_ * 64, 0, s, *g, \
+                           (const T*)x, (const T*)dy, dw, dw_ld, db, M, K, nt, mps, fd_hw, fd_w, zeros); \
+    }
+    // big layers: 256 x 128 tiles, one wave of workgroups; mid: 128 x 128; small: 64 x 64 with few
+    // splits (the f32 atomics of the epilogue are nsplit * K * N * 4 bytes at ~1.3 TB/s)
+    const long flops = 2L * M * K * N;
+    if (flops >= (1L << 36) && N >= 128 && K >= 256) LAUNCHW(256, 128, 4, 2, 3, 256)
+    else if (flops >= (1L << 32) && N >= 128 && K >= 128) LAUNCHW(128, 128, 2, 2, 3, 384)
+    else LAUNCHW(64, 64, 2, 2, 3, 384)
+#undef LAUNCHW
     return 0;
 }
 

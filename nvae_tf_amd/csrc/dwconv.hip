@@ -90,9 +90,89 @@ __global__ void k_dwconv5_wgrad(const T* __restrict__ x, const T* __restrict__ d
     if (db) atomicAdd(db + c, ab);
 }
 
+// LDS-resident variant for the shapes on the path (H*W <= 64): a workgroup owns 128 channels and a
+// chunk of images; per image the [HW][128] slabs of x and dy are staged in LDS once and every
+// (tap, channel) product reads them from there.  Thread = channel pair x tap group (taps tg, tg+4, ..),
+// lanes over consecutive channel pairs (conflict-free 4-B LDS reads).
+template <typename T>
+__global__ __launch_bounds__(256) void k_dwconv5_wgrad_lds(const T* __restrict__ x, const T* __restrict__ dy,
+                                                           float* dw, float* db, int B, int H, int W, int C,
+                                                           int imgs_per_block) {
+    constexpr int CS = 128;                        // channels per workgroup
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int HW = H * W;
+    T* sx = (T*)smem;
+    T* sdy = sx + HW * CS;
+    const int c_base = blockIdx.x * CS;
+    const int cp = threadIdx.x & 63, tg = threadIdx.x >> 6;      // channel pair, tap group
+    const int b0 = blockIdx.y * imgs_per_block;
+    int b1 = b0 + imgs_per_block;
+    if (b1 > B) b1 = B;
+    float acc[7][2];
+#pragma unroll
+    for (int t = 0; t < 7; ++t) acc[t][0] = acc[t][1] = 0.f;
+    float ab0 = 0.f, ab1 = 0.f;
+    constexpr int VE = 16 / sizeof(T);
+    const int chunks_per_row = CS / VE;
+    const int nchunks = HW * chunks_per_row;
+    for (int b = b0; b < b1; ++b) {
+        __syncthreads();
+        for (int q = threadIdx.x; q < nchunks; q += 256) {
+            int p = q / chunks_per_row, cc = (q - p * chunks_per_row) * VE;
+            uint4 vx = make_uint4(0, 0, 0, 0), vd = make_uint4(0, 0, 0, 0);
+            if (c_base + cc < C) {
+                long off = ((long)b * HW + p) * C + c_base + cc;
+                vx = *(const uint4*)(x + off);
+                vd = *(const uint4*)(dy + off);
+            }
+            *(uint4*)(sx + p * CS + cc) = vx;
+            *(uint4*)(sdy + p * CS + cc) = vd;
+        }
+        __syncthreads();
+        for (int p = 0; p < HW; ++p) {
+            const int h = p / W, wv = p - h * W;
+            const float g0 = ldf<T>(sdy + p * CS + 2 * cp), g1 = ldf<T>(sdy + p * CS + 2 * cp + 1);
+            if (tg == 0) { ab0 += g0; ab1 += g1; }
+#pragma unroll
+            for (int t = 0; t < 7; ++t) {
+                const int tap = tg + 4 * t;
+                if (tap >= 25) continue;
+                const int kh = tap / 5, kw = tap - kh * 5;
+                const int hi = h + kh - 2, wi = wv + kw - 2;
+                if (hi < 0 || hi >= H || wi < 0 || wi >= W) continue;
+                const T* xp = sx + (hi * W + wi) * CS + 2 * cp;
+                acc[t][0] += g0 * ldf<T>(xp);
+                acc[t][1] += g1 * ldf<T>(xp + 1);
+            }
+        }
+    }
+    const int c = c_base + 2 * cp;
+    if (c < C) {
+#pragma unroll
+        for (int t = 0; t < 7; ++t) {
+            const int tap = tg + 4 * t;
+            if (tap >= 25) continue;
+            atomicAdd(dw + (long)tap * C + c, acc[t][0]);
+            atomicAdd(dw + (long)tap * C + c + 1, acc[t][1]);
+        }
+        if (db && tg == 0) { atomicAdd(db + c, ab0); atomicAdd(db + c + 1, ab1); }
+    }
+}
+
 extern "C" int nvae_dwconv5_wgrad(int dtype, const void* x, const void* dy, float* dw, float* db, int B,
                                   int H, int W, int C, void* stream) {
     NVAE_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && x && dy && dw, "dwconv5_wgrad: bad args");
+    if (H * W <= 64 && C % 8 == 0 && aligned16(x) && aligned16(dy)) {
+        const int strips = cdiv(C, 128);
+        int want = 768 / strips;
+        if (want < 1) want = 1;
+        int ipb = cdiv(B, want);
+        if (ipb < 1) ipb = 1;
+        dim3 grid(strips, cdiv(B, ipb));
+        DISPATCH_T(dtype, hipLaunchKernelGGL((k_dwconv5_wgrad_lds<T>), grid, 256, (size_t)2 * H * W * 128 * sizeof(T), (hipStream_t)stream, (const T*)x, (const T*)dy, dw, db, B, H, W, C, ipb);)
+        NVAE_LAUNCH_CHECK("dwconv5_wgrad_lds");
+        return NVAE_OK;
+    }
     int cblocks = cdiv(C, 256);
     int want = 512 / cblocks;
     if (want < 1) want = 1;
