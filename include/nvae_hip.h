@@ -68,9 +68,13 @@ int nvae_conv_gemm(int dtype, const NvaeConvGeom* g, const void* src, const void
                    const float* bias, const void* residual, void* out, int out_f32, void* stream);
 /* Weight gradient: dw[k, n] += sum_m gather(x)[m, k] * dy[m, n]  (f32 atomics, dw zeroed or
  * holding a partial sum).  g describes the FORWARD conv; dy has pixel stride g->out_ld.
- * dw_ld = row stride of dw in floats.  db (may be NULL): db[n] += sum_m dy[m, n].               */
+ * dw_ld = row stride of dw in floats.  db (may be NULL): db[n] += sum_m dy[m, n].
+ * scratch (f32, uninitialised, may be NULL): when it holds nvae_conv_wgrad_scratch(...) floats the
+ * pixel reduction is split over up to 256 workgroups per tile and combined through it instead of
+ * through atomics.                                                                             */
+long nvae_conv_wgrad_scratch(int dtype, const NvaeConvGeom* g);
 int nvae_conv_wgrad(int dtype, const NvaeConvGeom* g, const void* x, const void* dy, float* dw,
-                    int dw_ld, float* db, void* stream);
+                    int dw_ld, float* db, float* scratch, long scratch_floats, void* stream);
 /* Scalar fallback for shapes the MFMA path does not take (Cin = 1, 20; Cout = 1).  w is the f32
  * master [KH, KW, *, *] addressed as w[tap*ws_tap + c*ws_c + n*ws_n] (tap order flipped if
  * flip != 0), so the same kernel serves forward and data-gradient.                              */

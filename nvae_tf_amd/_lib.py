@@ -39,7 +39,8 @@ _G = C.POINTER(ConvGeom)
 # name -> argtypes (the trailing stream argument is appended automatically)
 _SIGS = {
     "nvae_conv_gemm": [_i, _G, _p, _p, _i, _p, _p, _p, _i],
-    "nvae_conv_wgrad": [_i, _G, _p, _p, _p, _i, _p],
+    "nvae_conv_wgrad_scratch": None,
+    "nvae_conv_wgrad": [_i, _G, _p, _p, _p, _i, _p, _p, _l],
     "nvae_conv_direct": [_i, _G, _p, _p, _l, _l, _l, _i, _p, _p, _p, _i],
     "nvae_conv_direct_wgrad": [_i, _G, _p, _p, _p, _i, _p],
     "nvae_colsum": [_i, _p, _l, _i, _i, _p],
@@ -97,6 +98,8 @@ def load():
     lib.nvae_abi_version.restype = C.c_int
     lib.nvae_reduce_splits.restype = C.c_int
     lib.nvae_reduce_splits.argtypes = [_l, _i]
+    lib.nvae_conv_wgrad_scratch.restype = C.c_long
+    lib.nvae_conv_wgrad_scratch.argtypes = [_i, _G]
     for name, sig in _SIGS.items():
         if sig is None:
             continue

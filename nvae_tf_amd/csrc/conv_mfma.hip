@@ -205,19 +205,24 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <typename T, int BM, int BN, int WM, int WN, int STAGES>
+template <int BKC> __device__ __forceinline__ int swz_row(int row) {
+    return BKC == 8 ? ((row >> 1) & 7) : (row & 15);
+}
+
+template <typename T, int BM, int BN, int WM, int WN, int STAGES, int BKC>
 __global__ __launch_bounds__(WM* WN * 64) void k_conv_gemm2(
     NvaeConvGeom g, const T* __restrict__ src, const T* __restrict__ wT, int w_ld,
     const float* __restrict__ bias, const T* residual, void* out, int out_f32, int M, int K, int n_tiles,
     int total_tiles, FastDiv fd_hw, FastDiv fd_w, const uint4* __restrict__ zeros) {
     constexpr int NT = WM * WN * 64;
     constexpr int VE = Tr<T>::VE;
-    constexpr int BKE = 8 * VE;
-    constexpr int ACH = BM * 8 / NT, BCH = BN * 8 / NT;
+    constexpr int BKE = BKC * VE;                  // K elements per ring step (BKC 16-B chunks per row)
+    constexpr int ACH = BM * BKC / NT, BCH = BN * BKC / NT;
     constexpr int MI = BM / WM / 16, NI = BN / WN / 16;
-    constexpr int STAGE = (BM + BN) * 8;           // uint4 per ring slot
+    constexpr int STAGE = (BM + BN) * BKC;         // uint4 per ring slot
     constexpr int NLOAD = ACH + BCH;
-    static_assert(ACH >= 1 && BCH >= 1 && (NT / 8) % 16 == 0, "tile/thread mismatch");
+    static_assert(ACH >= 1 && BCH >= 1 && (NT / BKC) % 16 == 0, "tile/thread mismatch");
+    static_assert(BKC == 8 || BKC == 16, "row width");
     static_assert(STAGES == 2 || STAGES == 3, "ring depth");
     __shared__ uint4 lds[STAGES * STAGE];
 
@@ -229,9 +234,9 @@ __global__ __launch_bounds__(WM* WN * 64) void k_conv_gemm2(
     const int N = g.Cout;
     const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)lds;
 
-    // ---- per-thread gather state: chunk q = tid + NT*i  ->  row q>>3, physical slot q&7
-    const int row0 = tid >> 3;
-    const int kc = ((tid & 7) ^ ((row0 >> 1) & 7)) * VE;
+    // ---- per-thread gather state: chunk q = tid + NT*i  ->  row q / BKC, physical slot q % BKC
+    const int row0 = tid / BKC;
+    const int kc = ((tid % BKC) ^ swz_row<BKC>(row0)) * VE;
     int tap = kc / g.Cin;
     int ci = kc - tap * g.Cin;
     int kh = tap / g.KW, kw = tap - kh * g.KW;
@@ -243,7 +248,7 @@ __global__ __launch_bounds__(WM* WN * 64) void k_conv_gemm2(
     bool mv[ACH];
 #pragma unroll
     for (int i = 0; i < ACH; ++i) {
-        int m = bm * BM + row0 + (NT / 8) * i;
+        int m = bm * BM + row0 + (NT / BKC) * i;
         mv[i] = m < M;
         unsigned mm = mv[i] ? (unsigned)m : 0u;
         unsigned b = fdiv(mm, fd_hw);
@@ -258,7 +263,7 @@ __global__ __launch_bounds__(WM* WN * 64) void k_conv_gemm2(
     bool nv[BCH];
 #pragma unroll
     for (int j = 0; j < BCH; ++j) {
-        int n = bn * BN + row0 + (NT / 8) * j;
+        int n = bn * BN + row0 + (NT / BKC) * j;
         nv[j] = n < N;
         bp[j] = wT + (long)(nv[j] ? n : 0) * w_ld;
     }
@@ -281,7 +286,7 @@ __global__ __launch_bounds__(WM* WN * 64) void k_conv_gemm2(
 #pragma unroll
         for (int j = 0; j < BCH; ++j) {
             const void* p = (nv[j] && kval) ? (const void*)(bp[j] + kabs) : (const void*)zeros;
-            glds16(p, dst + (unsigned)(BM * 8 + NT * j) * 16u);
+            glds16(p, dst + (unsigned)(BM * BKC + NT * j) * 16u);
         }
         kabs += BKE;
         ci += BKE;
@@ -311,17 +316,17 @@ __global__ __launch_bounds__(WM* WN * 64) void k_conv_gemm2(
         if (t + STAGES - 1 < nk) issue(cur >= 1 ? cur - 1 : STAGES - 1);
         const uint4* buf = lds + cur * STAGE;
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
+        for (int h = 0; h < BKC / 4; ++h) {
             uint4 af[MI], bf[NI];
 #pragma unroll
             for (int i = 0; i < MI; ++i) {
                 int r = wm * (BM / WM) + i * 16 + fr;
-                af[i] = buf[r * 8 + ((h * 4 + fq) ^ ((r >> 1) & 7))];
+                af[i] = buf[r * BKC + ((h * 4 + fq) ^ swz_row<BKC>(r))];
             }
 #pragma unroll
             for (int j = 0; j < NI; ++j) {
                 int r = wn * (BN / WN) + j * 16 + fr;
-                bf[j] = buf[BM * 8 + r * 8 + ((h * 4 + fq) ^ ((r >> 1) & 7))];
+                bf[j] = buf[BM * BKC + r * BKC + ((h * 4 + fq) ^ swz_row<BKC>(r))];
             }
 #pragma unroll
             for (int i = 0; i < MI; ++i)
@@ -374,10 +379,10 @@ static int launch_conv_gemm(const NvaeConvGeom* g, const void* src, const void* 
     FastDiv fd_hw = make_fastdiv((unsigned)(g->Hout * g->Wout)), fd_w = make_fastdiv((unsigned)g->Wout);
     uint4* zeros = nullptr;
     (void)hipGetSymbolAddress((void**)&zeros, HIP_SYMBOL(g_zero16));
-#define LAUNCH2(BM_, BN_, WM_, WN_, ST_)                                                                \
+#define LAUNCH2(BM_, BN_, WM_, WN_, ST_, BKC_)                                                          \
     {                                                                                                   \
         int mt = cdiv(M, BM_), nt = cdiv(N, BN_);                                                       \
-        hipLaunchKernelGGL((k_conv_gemm2<T, BM_, BN_, WM_, WN_, ST_>), mt * nt, WM_ * WN_ * 64, 0, s, *g, \
+        hipLaunchKernelGGL((k_conv_gemm2<T, BM_, BN_, WM_, WN_, ST_, BKC_>), mt * nt, WM_ * WN_ * 64, 0, s, *g, \
                            (const T*)src, (const T*)wT, w_ld, bias, (const T*)residual, out, out_f32, M, \
                            K, nt, mt * nt, fd_hw, fd_w, zeros);                                         \
     }
@@ -387,13 +392,16 @@ static int launch_conv_gemm(const NvaeConvGeom* g, const void* src, const void* 
     const long w192 = (long)cdiv(N, 192) * 192, w128 = (long)cdiv(N, 128) * 128, w64 = (long)cdiv(N, 64) * 64;
     if ((long)cdiv(M, 256) * cdiv(N, 192) >= 224 && w192 <= w128 && w192 <= w64 && K >= 1024) {
         // the FLOP-dominant layers: 256 x 192 tile (112 FLOP per staged byte), 2-deep ring (112 KB)
-        LAUNCH2(256, 192, 4, 2, 2)
+        LAUNCH2(256, 192, 4, 2, 2, 8)
     } else if (big_tiles >= 192) {
-        if (w192 <= w128 && w192 <= w64) LAUNCH2(128, 192, 2, 4, 3)
-        else if (w128 <= w64) LAUNCH2(128, 128, 2, 4, 3)
-        else LAUNCH2(128, 64, 4, 2, 3)
+        if (w192 <= w128 && w192 <= w64) LAUNCH2(128, 192, 2, 4, 3, 8)
+        else if (w128 <= w64) LAUNCH2(128, 128, 2, 4, 3, 8)
+        else LAUNCH2(128, 64, 4, 2, 3, 8)
+    } else if (K >= 512) {
+        // small M: latency-bound K loop -> 8 waves, 128-deep ring steps (half the barriers)
+        LAUNCH2(64, 64, 2, 4, 3, 16)
     } else {
-        LAUNCH2(64, 64, 2, 2, 3)
+        LAUNCH2(64, 64, 2, 2, 3, 8)
     }
 #undef LAUNCH2
     return 0;
@@ -656,7 +664,7 @@ template <typename T, int KT, int NTL, int WK, int WN, int STAGES>
 __global__ __launch_bounds__(WK* WN * 64) void k_conv_wgrad2(
     NvaeConvGeom g, const T* __restrict__ x, const T* __restrict__ dy, float* dw, int dw_ld, float* db,
     int M, int K, int n_tiles, int m_per_split, FastDiv fd_hw, FastDiv fd_w,
-    const uint4* __restrict__ zeros) {
+    const uint4* __restrict__ zeros, float* slab) {
     constexpr int NT = WK * WN * 64;
     constexpr int VE = Tr<T>::VE;
     constexpr int RS = 8 * VE;                      // pixels per ring step
@@ -675,7 +683,9 @@ __global__ __launch_bounds__(WK* WN * 64) void k_conv_wgrad2(
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wk = wave / WN, wn = wave - wk * WN;
-    const int kt = blockIdx.x / n_tiles, nt = blockIdx.x - kt * n_tiles;
+    // consecutive tiles (the n-tiles of one k-tile, then the next k-tile) share an XCD's L2
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int kt = tile / n_tiles, nt = tile - kt * n_tiles;
     const int k0 = kt * KT, n0 = nt * NTL;
     const int N = g.Cout;
     const int m_begin = blockIdx.y * m_per_split;
@@ -823,6 +833,9 @@ __global__ __launch_bounds__(WK* WN * 64) void k_conv_wgrad2(
         cur = cur == STAGES - 1 ? 0 : cur + 1;
     }
 
+    // With a slab, every split writes its partial [K + 1][N] block (row K = bias) with plain stores and
+    // k_slab_reduce sums the splits; without, f32 atomics into the gradient buffer.
+    float* part = slab ? slab + (long)blockIdx.y * (K + 1) * N : nullptr;
     if (do_bias) {
         __syncthreads();
         float* red = (float*)lds;                    // [NT / CPR_B rows][CPR_B][VE]
@@ -830,12 +843,17 @@ __global__ __launch_bounds__(WK* WN * 64) void k_conv_wgrad2(
         for (int j = 0; j < VE; ++j) red[tid * VE + j] = bsum[j];
         __syncthreads();
         if (tid < CPR_B * VE) {
-            const int pc = tid / VE, j = tid - pc * VE;
-            // rows r hold physical chunk pc; their logical column depends on the row's swizzle
+            // logical column (chunk lc, element j): physical chunk differs per row through the swizzle
+            const int lc = tid / VE, j = tid - lc * VE;
+            float a = 0.f;
             for (int r = 0; r < NT / CPR_B; ++r) {
-                const int n = n0 + img_src_chunk<T, NTL>(r, pc) * VE + j;
-                float a = red[(r * CPR_B + pc) * VE + j];
-                if (n < N && a != 0.f) atomicAdd(db + n, a);
+                int pc = img_src_chunk<T, NTL>(r, lc);      // the swizzle is an involution
+                a += red[(r * CPR_B + pc) * VE + j];
+            }
+            const int n = n0 + lc * VE + j;
+            if (n < N) {
+                if (part) part[(long)K * N + n] = a;
+                else atomicAdd(db + n, a);
             }
         }
     }
@@ -848,52 +866,112 @@ __global__ __launch_bounds__(WK* WN * 64) void k_conv_wgrad2(
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int k = k0 + wk * (KT / WK) + i * 16 + fq * 4 + r;
-                if (k < K) atomicAdd(dw + (long)k * dw_ld + n, acc[i][j][r]);
+                if (k < K) {
+                    if (part) part[(long)k * N + n] = acc[i][j][r];
+                    else atomicAdd(dw + (long)k * dw_ld + n, acc[i][j][r]);
+                }
             }
     }
 }
 
+// dw[k*dw_ld + n] += sum_s slab[s][k][n]  (k < K);  db[n] += sum_s slab[s][K][n].  32 outputs per
+// workgroup, 8 lane groups walk the splits in parallel.
+__global__ void k_slab_reduce(const float* __restrict__ slab, int S, int K, int N, float* dw, int dw_ld,
+                              float* db) {
+    __shared__ float sm[8][32];
+    const int ol = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    const long total = (long)(K + 1) * N;
+    const long i = (long)blockIdx.x * 32 + ol;
+    float a = 0.f;
+    if (i < total)
+        for (int s = sl; s < S; s += 8) a += slab[(long)s * total + i];
+    sm[sl][ol] = a;
+    __syncthreads();
+    if (sl != 0 || i >= total) return;
+#pragma unroll
+    for (int k = 1; k < 8; ++k) a += sm[k][ol];
+    const int k = (int)(i / N), n = (int)(i - (long)k * N);
+    if (k < K) dw[(long)k * dw_ld + n] += a;
+    else if (db) db[n] += a;
+}
+
+// Split policy shared by the launcher and the scratch-size query.
+struct WgradPlan { int cfg, tiles, n_tiles, nsplit, mps; bool slab; };
+template <typename T>
+static WgradPlan plan_conv_wgrad(const NvaeConvGeom* g, long scratch_floats) {
+    constexpr int RS = 8 * Tr<T>::VE;
+    const int M = g->B * g->Hout * g->Wout, K = g->KH * g->KW * g->Cin, N = g->Cout;
+    const long flops = 2L * M * K * N;
+    WgradPlan p;
+    int KT, NTL;
+    if (flops >= (1L << 36) && N >= 128 && K >= 256) { p.cfg = 0; KT = 256; NTL = 128; }
+    else if (flops >= (1L << 32) && N >= 128 && K >= 128) { p.cfg = 1; KT = 128; NTL = 128; }
+    else { p.cfg = 2; KT = 64; NTL = 64; }
+    p.n_tiles = cdiv(N, NTL);
+    p.tiles = cdiv(K, KT) * p.n_tiles;
+    // enough workgroups to fill the chip (one wave of 256 for the 8-wave config, ~2 per CU otherwise),
+    // at least 4 ring steps each
+    int nsplit = (p.cfg == 0 ? 256 : 512) / p.tiles;
+    int max_split = M / (RS * 4);
+    if (nsplit > max_split) nsplit = max_split;
+    if (nsplit > 256) nsplit = 256;
+    if (nsplit < 1) nsplit = 1;
+    auto settle = [&](int want) {
+        int mps = cdiv(M, want);
+        mps = ((mps + RS - 1) / RS) * RS;
+        p.mps = mps;
+        p.nsplit = cdiv(M, mps);
+    };
+    settle(nsplit);
+    // > 4 splits are combined through a slab (same-address f32 atomics serialise, ~0.3 us each);
+    // without enough scratch fall back to 4 atomically combined splits
+    p.slab = p.nsplit > 4;
+    if (p.slab && scratch_floats < (long)p.nsplit * (K + 1) * N) {
+        p.slab = false;
+        settle(4);
+    }
+    return p;
+}
+
 template <typename T>
 static int launch_conv_wgrad(const NvaeConvGeom* g, const void* x, const void* dy, float* dw, int dw_ld,
-                             float* db, hipStream_t s) {
-    constexpr int RS = 8 * Tr<T>::VE;
+                             float* db, float* scratch, long scratch_floats, hipStream_t s) {
     const int M = g->B * g->Hout * g->Wout, K = g->KH * g->KW * g->Cin, N = g->Cout;
     FastDiv fd_hw = make_fastdiv((unsigned)(g->Hout * g->Wout)), fd_w = make_fastdiv((unsigned)g->Wout);
     uint4* zeros = nullptr;
     (void)hipGetSymbolAddress((void**)&zeros, HIP_SYMBOL(g_zero16));
-#define LAUNCHW(KT_, NTL_, WK_, WN_, ST_, TARGET_)                                                      \
-    {                                                                                                   \
-        const int kt = cdiv(K, KT_), nt = cdiv(N, NTL_), tiles = kt * nt;                               \
-        int nsplit = (TARGET_) / tiles;                                                                 \
-        int max_split = M / (RS * 4);                                                                   \
-        if (nsplit > max_split) nsplit = max_split;                                                     \
-        if (nsplit < 1) nsplit = 1;                                                                     \
-        int mps = cdiv(M, nsplit);                                                                      \
-        mps = ((mps + RS - 1) / RS) * RS;                                                               \
-        nsplit = cdiv(M, mps);                                                                          \
-        dim3 grid(tiles, nsplit);                                                                       \
-        hipLaunchKernelGGL((k_conv_wgrad2<T, KT_, NTL_, WK_, WN_, ST_>), grid, WK_ * WN_ * 64, 0, s, *g, \
-                           (const T*)x, (const T*)dy, dw, dw_ld, db, M, K, nt, mps, fd_hw, fd_w, zeros); \
-    }
-    // big layers: 256 x 128 tiles, one wave of workgroups; mid: 128 x 128; small: 64 x 64 with few
-    // splits (the f32 atomics of the epilogue are nsplit * K * N * 4 bytes at ~1.3 TB/s)
-    const long flops = 2L * M * K * N;
-    if (flops >= (1L << 36) && N >= 128 && K >= 256) LAUNCHW(256, 128, 4, 2, 3, 256)
-    else if (flops >= (1L << 32) && N >= 128 && K >= 128) LAUNCHW(128, 128, 2, 2, 3, 384)
-    else LAUNCHW(64, 64, 2, 2, 3, 384)
+    const WgradPlan p = plan_conv_wgrad<T>(g, scratch ? scratch_floats : 0);
+    float* slab = p.slab ? scratch : nullptr;
+    dim3 grid(p.tiles, p.nsplit);
+#define LAUNCHW(KT_, NTL_, WK_, WN_, ST_)                                                               \
+    hipLaunchKernelGGL((k_conv_wgrad2<T, KT_, NTL_, WK_, WN_, ST_>), grid, WK_ * WN_ * 64, 0, s, *g,    \
+                       (const T*)x, (const T*)dy, dw, dw_ld, db, M, K, p.n_tiles, p.mps, fd_hw, fd_w,   \
+                       zeros, slab);
+    if (p.cfg == 0) LAUNCHW(256, 128, 4, 2, 3)
+    else if (p.cfg == 1) LAUNCHW(128, 128, 2, 2, 3)
+    else LAUNCHW(64, 64, 2, 2, 3)
 #undef LAUNCHW
+    if (slab)
+        hipLaunchKernelGGL(k_slab_reduce, cdiv((long)(K + 1) * N, 32), 256, 0, s, slab, p.nsplit, K, N, dw, dw_ld, db);
     return 0;
 }
 
+extern "C" long nvae_conv_wgrad_scratch(int dtype, const NvaeConvGeom* g) {
+    if (!g) return 0;
+    const long K = (long)g->KH * g->KW * g->Cin, N = g->Cout;
+    WgradPlan p = dtype == NVAE_BF16 ? plan_conv_wgrad<bf16>(g, 1L << 60) : plan_conv_wgrad<float>(g, 1L << 60);
+    return p.slab ? (long)p.nsplit * (K + 1) * N : 0;
+}
+
 extern "C" int nvae_conv_wgrad(int dtype, const NvaeConvGeom* g, const void* x, const void* dy, float* dw,
-                               int dw_ld, float* db, void* stream) {
+                               int dw_ld, float* db, float* scratch, long scratch_floats, void* stream) {
     if (int e = check_geom_mfma("conv_wgrad", g)) return e;
     NVAE_REQUIRE(x && dy && dw && dw_ld >= g->Cout, "conv_wgrad: bad args");
     const int ve = (dtype == NVAE_BF16) ? 8 : 4;
     NVAE_REQUIRE(g->Cin % ve == 0 && g->in_ld % ve == 0 && g->Cout % ve == 0 && g->out_ld % ve == 0,
                  "conv_wgrad: Cin=%d Cout=%d and their lds must be multiples of %d (use nvae_conv_direct_wgrad)", g->Cin, g->Cout, ve);
     NVAE_REQUIRE(aligned16(x) && aligned16(dy), "conv_wgrad: x/dy must be 16-B aligned");
-    DISPATCH_T(dtype, launch_conv_wgrad<T>(g, x, dy, dw, dw_ld, db, (hipStream_t)stream);)
+    DISPATCH_T(dtype, launch_conv_wgrad<T>(g, x, dy, dw, dw_ld, db, scratch, scratch_floats, (hipStream_t)stream);)
     NVAE_LAUNCH_CHECK("conv_wgrad");
     return NVAE_OK;
 }

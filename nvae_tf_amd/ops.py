@@ -168,7 +168,9 @@ def conv2d(ctx: Ctx, x: Var, conv, *, stride: int = 1, up: int = 1, pad: Optiona
             w_mfma = (cin % ve == 0 and Cx % ve == 0 and cout % ve == 0 and Cy % ve == 0
                       and out_coff % ve == 0)
             if w_mfma:
-                call("nvae_conv_wgrad", ctx.dt, C.byref(gw), ptr(x.t), dy_ptr, dw, cout, db)
+                need = L.load().nvae_conv_wgrad_scratch(ctx.dt, C.byref(gw))
+                scratch = ctx.empty((need,), torch.float32) if need else None
+                call("nvae_conv_wgrad", ctx.dt, C.byref(gw), ptr(x.t), dy_ptr, dw, cout, db, ptr(scratch), need)
             else:
                 call("nvae_conv_direct_wgrad", ctx.dt, C.byref(gw), ptr(x.t), dy_ptr, dw, cout, db)
             # ---- residual
