@@ -297,11 +297,13 @@ class NVAE:
         torch.cuda.synchronize(self.device)
         pool = torch.cuda.graph_pool_handle()
         g1, g2, g3 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g1, pool=pool):
+        # thread_local: a NCCL/RCCL watchdog thread may touch the HIP API while we capture
+        kw = dict(pool=pool, capture_error_mode="thread_local")
+        with torch.cuda.graph(g1, **kw):
             ctx = self._seg_forward(self._static_x, None)
-        with torch.cuda.graph(g2, pool=pool):
+        with torch.cuda.graph(g2, **kw):
             self._seg_backward(ctx, B)
-        with torch.cuda.graph(g3, pool=pool):
+        with torch.cuda.graph(g3, **kw):
             self._seg_update()
         self._plan = (g1, g2, g3, B)
         return self

@@ -1,0 +1,177 @@
+"""Command-line driver mirroring the reference's train.py: the same flags and defaults
+(train.py:145-297), modes train / test / sample, Adamax + cosine LR, periodic checkpoints.
+
+Differences, all deliberate (SURVEY "Quirks"): --n_groups_per_scale is parsed as ints (Q13); resume
+restores the step counter as epochs * batches_per_epoch (Q14); data come from local files or
+--synthetic; --dtype selects bf16 (default) or f32 compute; launched under torchrun the batch is
+sharded over ranks (one process per GPU, RCCL gradient all-reduce)."""
+from __future__ import annotations
+
+import os
+import random
+import time
+from argparse import ArgumentParser
+
+import numpy as np
+import torch
+
+
+def checkpoint_path(model_save_dir, epoch):
+    return os.path.join(model_save_dir, f"epoch_{epoch}.pt")
+
+
+def save_checkpoint(model, path, epoch):
+    os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
+    ps = model.ps
+    torch.save({"params": ps.params.cpu(), "state": ps.state.cpu(), "adam_m": ps.adam_m.cpu(),
+                "adam_u": ps.adam_u.cpu(), "steps": model.steps, "opt_iterations": model.opt_iterations,
+                "epoch": epoch, "rng_counter": model.rng_counter.cpu()}, path)
+
+
+def load_checkpoint(model, path):
+    ck = torch.load(path, map_location="cpu", weights_only=True)
+    ps = model.ps
+    ps.params.copy_(ck["params"]); ps.state.copy_(ck["state"])
+    ps.adam_m.copy_(ck["adam_m"]); ps.adam_u.copy_(ck["adam_u"])
+    model.steps, model.opt_iterations = int(ck["steps"]), int(ck["opt_iterations"])
+    model.rng_counter.copy_(ck["rng_counter"])
+    return int(ck["epoch"])
+
+
+def train(args, model, train_data, test_data, rank=0, world=1):
+    from .util import sample_to_dir
+    best, bad_epochs = float("inf"), 0
+    use_graph = not args.no_graph
+    captured = False
+    for epoch in range(args.resume_from, args.epochs):
+        model.on_epoch_begin(epoch)
+        t0, seen, losses = time.time(), 0, []
+        for i, (images, _) in enumerate(train_data):
+            images = images[rank::world] if world > 1 else images       # shard the batch over ranks
+            if use_graph and images.shape[0] == args.batch_size // world:
+                if not captured:
+                    model.capture_train_step(images.shape)
+                    captured = True
+                out = model.train_step_graphed(images)
+            else:
+                out = model.train_step(images)
+            seen += images.shape[0] * world
+            if args.verbose or args.debug or i % 50 == 0:
+                losses.append(float(out["loss"]))
+        dt = time.time() - t0
+        if rank == 0:
+            print(f"epoch {epoch}: loss {np.mean(losses):.3f}  {seen / dt:.1f} images/s  beta {model.beta():.3f}")
+            if epoch % args.sample_frequency == 0:
+                sample_to_dir(model, 16, 16, 1.0, os.path.join(args.sample_dir, f"epoch_{epoch}"))
+            if epoch % args.model_save_frequency == 0:
+                save_checkpoint(model, checkpoint_path(args.model_save_dir, epoch), epoch)
+        if args.patience:          # EarlyStopping on the training loss (train.py:35-38)
+            cur = float(np.mean(losses))
+            best, bad_epochs = (cur, 0) if cur < best else (best, bad_epochs + 1)
+            if bad_epochs > args.patience:
+                break
+    if rank == 0:
+        save_checkpoint(model, checkpoint_path(args.model_save_dir, "final"), args.epochs)
+
+
+def test(args, model, test_data):
+    from .evaluate import evaluate_model
+    evaluation = evaluate_model(epoch=args.resume_from, model=model, test_data=test_data, n_attempts=10)
+    print(f"Negative log likelihood: {evaluation.nll}")
+    print(evaluation)
+
+
+def sample(args, model):
+    from .util import sample_to_dir
+    for t in [0.7, 0.8, 0.9, 1]:                      # train.py:76-80
+        output_dir = os.path.join(args.sample_dir, f"t_{t:.1f}")
+        os.makedirs(output_dir, exist_ok=True)
+        sample_to_dir(model, args.batch_size, args.n_samples, t, output_dir)
+
+
+def main(args):
+    from . import parallel
+    from .datasets import load_mnist
+    from .models import NVAE
+    print(f"Args: {args}")
+    rank, world, local = parallel.init_from_env()
+    if args.cpu or not torch.cuda.is_available():
+        raise SystemExit("the NVAE hot path runs on an MI355X through libnvae_hip.so; there is no CPU path "
+                         "(the CPU oracle under oracle/ is test infrastructure only)")
+    torch.cuda.set_device(local)
+    torch.manual_seed(args.seed); random.seed(args.seed); np.random.seed(args.seed)
+    train_data, test_data = load_mnist(args.batch_size, binary=args.mode == "train" or args.binary_eval,
+                                       data_dir=args.data_dir, synthetic=args.synthetic)
+    if args.debug:
+        train_data, test_data = train_data.take(4), test_data.take(4)
+    batches_per_epoch = len(train_data)
+    model = NVAE(n_encoder_channels=args.n_encoder_channels, n_decoder_channels=args.n_decoder_channels,
+                 res_cells_per_group=args.res_cells_per_group, n_preprocess_blocks=args.n_preprocess_blocks,
+                 n_preprocess_cells=args.n_preprocess_cells, n_latent_per_group=args.n_latent_per_group,
+                 n_latent_scales=len(args.n_groups_per_scale), n_groups_per_scale=args.n_groups_per_scale,
+                 n_postprocess_blocks=args.n_postprocess_blocks, n_post_process_cells=args.n_postprocess_cells,
+                 sr_lambda=args.sr_lambda, scale_factor=args.scale_factor, total_epochs=args.epochs,
+                 n_total_iterations=batches_per_epoch * args.epochs, step_based_warmup=args.step_based_warmup,
+                 input_shape=[args.batch_size // world, 32, 32, 1], device=f"cuda:{local}",
+                 dtype=torch.bfloat16 if args.dtype == "bf16" else torch.float32, seed=args.seed + rank,
+                 lr_decay_steps=args.epochs * batches_per_epoch)
+    if world > 1:
+        import torch.distributed as dist
+        model.reducer = parallel.GradReducer()
+        dist.broadcast(model.ps.params, 0); dist.broadcast(model.ps.state, 0)
+    if args.resume_from > 0:
+        load_checkpoint(model, checkpoint_path(args.model_save_dir, args.resume_from))
+        model.steps = args.resume_from * batches_per_epoch      # Q14 fixed (reference: * batch_size)
+    if args.mode == "train":
+        train(args, model, train_data, test_data, rank, world)
+    elif args.mode == "test":
+        test(args, model, test_data)
+    elif args.mode == "sample":
+        sample(args, model)
+
+
+def parse_args(argv=None):
+    p = ArgumentParser()
+    p.add_argument("--epochs", type=int, default=400, help="Number of epochs to train")
+    p.add_argument("--batch_size", default=144, type=int)
+    p.add_argument("--mode", type=str, choices=["train", "test", "sample"])
+    p.add_argument("--n_encoder_channels", type=int, default=32)
+    p.add_argument("--n_decoder_channels", type=int, default=32)
+    p.add_argument("--res_cells_per_group", type=int, default=1)
+    p.add_argument("--n_preprocess_blocks", type=int, default=2)
+    p.add_argument("--n_preprocess_cells", type=int, default=3)
+    p.add_argument("--n_postprocess_blocks", type=int, default=2)
+    p.add_argument("--n_postprocess_cells", type=int, default=3)
+    p.add_argument("--n_latent_per_group", type=int, default=20)
+    p.add_argument("--n_groups_per_scale", nargs="+", type=int, default=[5, 10])
+    p.add_argument("--sr_lambda", type=float, default=0.01, help="Spectral regularisation strength")
+    p.add_argument("--scale_factor", type=int, default=2)
+    p.add_argument("--dataset", type=str, choices=["mnist"], default="mnist")
+    p.add_argument("--cpu", action="store_true", help="(reference flag) not supported: no CPU path")
+    p.add_argument("--debug", action="store_true", help="Use only the first four batches of data")
+    p.add_argument("--n_samples", type=int, default=10)
+    p.add_argument("--verbose", action="store_true")
+    p.add_argument("--model_save_dir", type=str, default="models")
+    p.add_argument("--sample_dir", type=str, default="results")
+    p.add_argument("--resume_from", type=int, default=0, help="Epoch to resume training from")
+    p.add_argument("--tensorboard_log_dir", type=str, default="logs")
+    p.add_argument("--sample_frequency", type=int, default=5)
+    p.add_argument("--evaluate_frequency", type=int, default=10)
+    p.add_argument("--log_frequency", type=int, default=1)
+    p.add_argument("--binary_eval", action="store_true", help="Evaluate on binary data")
+    p.add_argument("--patience", type=int)
+    p.add_argument("--model_save_frequency", type=int, default=10)
+    p.add_argument("--step_based_warmup", action="store_true")
+    p.add_argument("--workers", type=int, default=1)
+    p.add_argument("--multiprocessing", action="store_true")
+    p.add_argument("--seed", type=int, default=1)
+    # additions of this build
+    p.add_argument("--dtype", choices=["bf16", "f32"], default="bf16", help="compute dtype of the HIP path")
+    p.add_argument("--data_dir", type=str, default=None, help="directory with mnist.npz or the IDX files")
+    p.add_argument("--synthetic", action="store_true", help="random MNIST-shaped data (no files needed)")
+    p.add_argument("--no_graph", action="store_true", help="launch eagerly instead of replaying hipGraphs")
+    return p.parse_args(argv)
+
+
+if __name__ == "__main__":
+    main(parse_args())

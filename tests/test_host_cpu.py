@@ -1,0 +1,105 @@
+"""CPU tests of the host side: the C-ABI library loads and exports every entry point the header
+declares, the module tree reproduces the reference's parameter totals and schedules, and the
+data-parallel reducer works over gloo with world_size 2."""
+import math
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol(lib):
+    hdr = open(os.path.join(ROOT, "include", "nvae_hip.h")).read()
+    declared = set(re.findall(r"\b(nvae_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 40
+    from nvae_tf_amd import _lib
+    assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.nvae_abi_version() == 1
+    assert lib.nvae_reduce_splits(131072, 192) >= 1
+
+
+def make(groups, cells, dtype=torch.bfloat16, **kw):
+    from nvae_tf_amd.models import NVAE
+    return NVAE(32, 32, cells, 2, 3, 20, len(groups), groups, 2, 3, 0.01, 2, 400, 1000, True, [1, 32, 32, 1],
+                device="cpu", dtype=dtype, **kw)
+
+
+def test_module_tree_matches_reference_parameter_totals(lib):
+    for groups, cells, want in (([5, 10], 1, 40128893), ([1, 1], 1, 17243405), ([5, 10], 2, 62225021)):
+        m = make(groups, cells)
+        assert m.n_trainable() == want
+    m = make([5, 10], 1)
+    assert len(m.ps.bn_loss_layers) == 88 and len(m.ps.convs) == 163
+    assert m.eps_shapes(3) == [(3, 4, 4, 20)] * 10 + [(3, 8, 8, 20)] * 5
+    # names line up with the oracle's (weights are exchanged by name)
+    from oracle.nvae_oracle import OracleConfig, OracleNVAE
+    orc = OracleNVAE(OracleConfig(), dtype=torch.float32)
+    assert set(orc.s.params) == set(m.ps.slots) and set(orc.s.state) == set(m.ps.sslots)
+    for k, v in orc.s.params.items():
+        assert tuple(v.shape) == m.ps.slots[k].shape, k
+
+
+def test_schedules_and_alphas(lib):
+    m = make([5, 10], 1)
+    assert m.alphas.tolist() == [1.0] * 10 + [8.0] * 5
+    assert m.calculate_kl_alphas(2, [1, 1]).tolist() == [1.0, 4.0]
+    m.steps = 0
+    assert m.beta() == 0
+    m.steps = 150
+    assert abs(m.beta() - 0.5) < 1e-12
+    m.steps = 10 ** 6
+    assert m.beta() == 1
+    assert abs(m.learning_rate(0) - 1e-3) < 1e-15 and abs(m.learning_rate(500) - 5e-4) < 1e-12
+    assert m.learning_rate(5000) < 1e-12
+    from nvae_tf_amd.ops import same_pad
+    assert same_pad(32, 3, 2) == (0, 1) and same_pad(8, 5, 1) == (2, 2) and same_pad(31, 1, 2) == (0, 0)
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    from nvae_tf_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libnvae_hip.so")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        _lib.load()
+
+
+def _reducer_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from nvae_tf_amd.parallel import GradReducer
+    red = GradReducer(bucket_bytes=4096)     # many buckets
+    n = 10_000 + 3
+    flat = torch.arange(n, dtype=torch.float32) * (rank + 1)
+    red.allreduce_grads_(flat)
+    am = torch.tensor([1.0, 2.0, 3.0]) * (rank + 1)
+    red.allreduce_mean_(am)
+    buckets = red.buckets(n)
+    q.put((rank, flat[:5].tolist(), float(flat.sum()), am.tolist(), buckets[0].stop, buckets[-1].start,
+           sum(b.stop - b.start for b in buckets)))
+    dist.destroy_process_group()
+
+
+def test_grad_reducer_gloo_world2():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_reducer_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    n = 10_003
+    for rank, head, tot, am, first_stop, last_start, covered in res:
+        assert head == [0.0, 1.5, 3.0, 4.5, 6.0]                 # mean of 1x and 2x
+        assert abs(tot - 1.5 * n * (n - 1) / 2) / tot < 1e-6
+        assert am == [1.5, 3.0, 4.5]
+        assert first_stop == n and last_start == 0 and covered == n   # end of the buffer first
