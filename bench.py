@@ -156,6 +156,12 @@ def main():
         avg_ms = sum(k["ms"] for k in kern) / len(kern)
         flops_per_launch = 2.0 * args.batch * 943.7184e6   # both 5x5 shapes: 943.7 M MAC per image
         achieved = flops_per_launch / avg_ms / 1e9
+        traffic = None     # HBM-side bytes per launch from the PMC passes committed under profiles/
+        pmc = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_dominant.json")) \
+            if os.path.isdir(os.path.join(ROOT, "profiles")) else []
+        if pmc:
+            with open(os.path.join(ROOT, "profiles", pmc[-1])) as fh:
+                traffic = json.load(fh).get("traffic_bytes_avg")
         res = {
             "metric": "train_images_per_sec", "value": value, "unit": "images/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -170,7 +176,9 @@ def main():
             "e2e_mfma_frac": value / world * TRAIN_FLOP_PER_IMG / 1e12 / PEAK_BF16_TFLOPS,
             "roofline": {"bound": "mfma", "kernel": "k_conv_gemm2<bf16,256,192,4,2,2,8> (dense 5x5 implicit GEMM of Postprocess, fwd + dgrad)",
                          "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_BF16_TFLOPS, "traffic": None,
+                         "frac": achieved / PEAK_BF16_TFLOPS, "traffic": traffic,
+                         "traffic_unit": "bytes per launch (2*FETCH_SIZE + WRITE_SIZE, rocprofv3 --pmc)",
+                         "algorithmic_bytes": 0.5 * (57704448 + 102506496),
                          "avg_launch_ms": avg_ms, "shapes": kern},
         }
         if world == 1 and not args.no_cpu_baseline:
