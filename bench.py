@@ -57,7 +57,7 @@ def time_dominant_kernel(model, batch, iters=20):
 
         def launch():
             L.call("nvae_conv_gemm", L.dtype_code(model.dtype), C.byref(g), L.ptr(x), wT, conv.wf_ld, None,
-                   None, L.ptr(y), 0)
+                   None, L.ptr(y), 0, None)
         for _ in range(3):
             launch()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -64,8 +64,13 @@ typedef struct NvaeConvGeom {
 /* MFMA implicit GEMM.  wT: [Cout][w_ld] (k contiguous, k = (kh*KW+kw)*Cin + c), element type
  * `dtype`.  bias (f32, may be NULL), residual (dtype, may be NULL; may alias out = accumulate).
  * Requires Cin, in_ld, w_ld multiples of 8 (bf16) / 4 (f32) and 16-B aligned src/wT.            */
+/* stats (f32, may be NULL): [nvae_conv_gemm_mtiles(g)][2][Cout] per-M-tile column sums and sums of
+ * squares of the output (bias included) - the BatchNorm statistics slab of the layer that follows,
+ * consumed by nvae_bn_finalize_s.                                                                */
+int nvae_conv_gemm_mtiles(const NvaeConvGeom* g);
 int nvae_conv_gemm(int dtype, const NvaeConvGeom* g, const void* src, const void* wT, int w_ld,
-                   const float* bias, const void* residual, void* out, int out_f32, void* stream);
+                   const float* bias, const void* residual, void* out, int out_f32, float* stats,
+                   void* stream);
 /* Weight gradient: dw[k, n] += sum_m gather(x)[m, k] * dy[m, n]  (f32 atomics, dw zeroed or
  * holding a partial sum).  g describes the FORWARD conv; dy has pixel stride g->out_ld.
  * dw_ld = row stride of dw in floats.  db (may be NULL): db[n] += sum_m dy[m, n].
@@ -105,6 +110,10 @@ int nvae_bn_stats(int dtype, const void* x, long rows, int C, float* partials, v
 int nvae_bn_finalize(const float* partials, long rows, int C, const float* gamma, const float* beta,
                      float* running_mean, float* running_var, float momentum, float eps,
                      float* scale, float* shift, float* mean, float* invstd, void* stream);
+/* as nvae_bn_finalize for a slab with an explicit number of row splits S (conv-epilogue statistics) */
+int nvae_bn_finalize_s(const float* partials, int S, long rows, int C, const float* gamma,
+                       const float* beta, float* running_mean, float* running_var, float momentum,
+                       float eps, float* scale, float* shift, float* mean, float* invstd, void* stream);
 int nvae_bn_eval_prepare(const float* gamma, const float* beta, const float* running_mean,
                          const float* running_var, int C, float eps, float* scale, float* shift,
                          void* stream);

@@ -38,7 +38,8 @@ _G = C.POINTER(ConvGeom)
 
 # name -> argtypes (the trailing stream argument is appended automatically)
 _SIGS = {
-    "nvae_conv_gemm": [_i, _G, _p, _p, _i, _p, _p, _p, _i],
+    "nvae_conv_gemm_mtiles": None,
+    "nvae_conv_gemm": [_i, _G, _p, _p, _i, _p, _p, _p, _i, _p],
     "nvae_conv_wgrad_scratch": None,
     "nvae_conv_wgrad": [_i, _G, _p, _p, _p, _i, _p, _p, _l],
     "nvae_conv_direct": [_i, _G, _p, _p, _l, _l, _l, _i, _p, _p, _p, _i],
@@ -49,6 +50,7 @@ _SIGS = {
     "nvae_reduce_splits": None,
     "nvae_bn_stats": [_i, _p, _l, _i, _p],
     "nvae_bn_finalize": [_p, _l, _i, _p, _p, _p, _p, _f, _f, _p, _p, _p, _p],
+    "nvae_bn_finalize_s": [_p, _i, _l, _i, _p, _p, _p, _p, _f, _f, _p, _p, _p, _p],
     "nvae_bn_eval_prepare": [_p, _p, _p, _p, _i, _f, _p, _p],
     "nvae_bn_apply": [_i, _p, _p, _l, _i, _p, _p, _i],
     "nvae_bn_bwd_reduce": [_i, _p, _p, _l, _i, _p, _p, _i, _p],
@@ -98,6 +100,8 @@ def load():
     lib.nvae_abi_version.restype = C.c_int
     lib.nvae_reduce_splits.restype = C.c_int
     lib.nvae_reduce_splits.argtypes = [_l, _i]
+    lib.nvae_conv_gemm_mtiles.restype = C.c_int
+    lib.nvae_conv_gemm_mtiles.argtypes = [_G]
     lib.nvae_conv_wgrad_scratch.restype = C.c_long
     lib.nvae_conv_wgrad_scratch.argtypes = [_i, _G]
     for name, sig in _SIGS.items():

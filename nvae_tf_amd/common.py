@@ -47,12 +47,13 @@ class Rescaler:
         self.bn = ps.bn(name + ".bn", in_channels, in_bn_loss)
         self.conv = ps.conv(name + ".conv", 3, in_channels, n_channels)
         self.mode = rescale_type
+        self.feeds_bn = False      # set by the owner when the output goes straight into a BatchNorm
         self.factor = scale_factor
 
     def __call__(self, ctx: Ctx, x: Var) -> Var:
         y = ops.bn_act(ctx, x, self.bn, L.ACT_SWISH)
         if self.mode == RescaleType.UP:
-            return ops.conv2d(ctx, y, self.conv, up=self.factor)
+            return ops.conv2d(ctx, y, self.conv, up=self.factor, want_stats=self.feeds_bn)
         return ops.conv2d(ctx, y, self.conv, stride=self.factor)
 
 

@@ -193,6 +193,16 @@ extern "C" int nvae_bn_finalize(const float* partials, long rows, int C, const f
     return NVAE_OK;
 }
 
+extern "C" int nvae_bn_finalize_s(const float* partials, int S, long rows, int C, const float* gamma,
+                                  const float* beta, float* rm, float* rv, float momentum, float eps,
+                                  float* scale, float* shift, float* mean, float* invstd, void* stream) {
+    NVAE_REQUIRE(rows > 0 && C > 0 && S > 0, "bn_finalize_s: bad shape");
+    hipLaunchKernelGGL(k_bn_finalize, cdiv(C, 32), 256, 0, (hipStream_t)stream, partials, S, 1.0f / (float)rows,
+                       C, gamma, beta, rm, rv, momentum, eps, scale, shift, mean, invstd);
+    NVAE_LAUNCH_CHECK("bn_finalize_s");
+    return NVAE_OK;
+}
+
 __global__ void k_bn_eval_prepare(const float* gamma, const float* beta, const float* rm,
                                   const float* rv, int C, float eps, float* scale, float* shift) {
     int c = blockIdx.x * 256 + threadIdx.x;

@@ -46,142 +46,6 @@ __device__ __forceinline__ void mfma_step(const uint4& a, const uint4& b, f32x4&
     }
 }
 
-template <typename T, int BN>
-__global__ __launch_bounds__(256, 2) void k_conv_gemm(NvaeConvGeom g, const T* __restrict__ src,
-                                                      const T* __restrict__ wT, int w_ld,
-                                                      const float* __restrict__ bias, const T* residual,
-                                                      void* out, int out_f32, int M, int K, int n_tiles,
-                                                      int total_tiles, FastDiv fd_hw, FastDiv fd_w) {
-    constexpr int BM = 128;
-    constexpr int VE = Tr<T>::VE;
-    constexpr int BKE = 4 * VE;
-    constexpr int NI = BN / 32;        // 16-wide n blocks per wave
-    constexpr int BCH = BN / 64;       // B chunks per thread
-    __shared__ uint4 lds[2][(BM + BN) * 4];
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int tile = xcd_remap(blockIdx.x, total_tiles);
-    const int bm = tile / n_tiles, bn = tile - bm * n_tiles;
-    const int N = g.Cout;
-
-    // ---- per-thread gather state -------------------------------------------------------
-    const int slot = tid & 3, row0 = tid >> 2;
-    const int kc = (slot ^ swz4(row0)) * VE;       // this thread's element offset inside a K-step
-    int tap = kc / g.Cin;
-    int ci = kc - tap * g.Cin;
-    int kh = tap / g.KW, kw = tap - kh * g.KW;
-    int kabs = kc;
-    const int hlim = g.Hin * g.div, wlim = g.Win * g.div;
-
-    int hb[2], wb[2];
-    long pb[2];
-    bool mv[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        int m = bm * BM + row0 + 64 * i;
-        mv[i] = m < M;
-        unsigned mm = mv[i] ? (unsigned)m : 0u;
-        unsigned b = fdiv(mm, fd_hw);
-        unsigned rem = mm - b * fd_hw.d;
-        unsigned ho = fdiv(rem, fd_w);
-        unsigned wo = rem - ho * fd_w.d;
-        hb[i] = (int)ho * g.stride - g.pad_t;
-        wb[i] = (int)wo * g.stride - g.pad_l;
-        pb[i] = (long)b * g.Hin * g.Win;
-    }
-    const T* bp[BCH];
-    bool nv[BCH];
-#pragma unroll
-    for (int j = 0; j < BCH; ++j) {
-        int n = bn * BN + row0 + 64 * j;
-        nv[j] = n < N;
-        bp[j] = wT + (long)(nv[j] ? n : 0) * w_ld;
-    }
-
-    uint4 ra[2], rb[BCH];
-    auto load_step = [&]() {
-        const bool kval = kabs < K;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            int hc = hb[i] + kh, wc = wb[i] + kw;
-            bool ok = mv[i] && kval && hc >= 0 && hc < hlim && wc >= 0 && wc < wlim;
-            int hs = hc, ws = wc;
-            if (g.div != 1) {
-                hs = hc / g.div; ws = wc / g.div;
-                if (g.exact) ok = ok && (hs * g.div == hc) && (ws * g.div == wc);
-            }
-            ra[i] = make_uint4(0, 0, 0, 0);
-            if (ok) ra[i] = *(const uint4*)(src + (pb[i] + (long)hs * g.Win + ws) * g.in_ld + ci);
-        }
-#pragma unroll
-        for (int j = 0; j < BCH; ++j) {
-            rb[j] = make_uint4(0, 0, 0, 0);
-            if (nv[j] && kval) rb[j] = *(const uint4*)(bp[j] + kabs);
-        }
-        kabs += BKE;
-        ci += BKE;
-        while (ci >= g.Cin) {
-            ci -= g.Cin;
-            if (++kw == g.KW) { kw = 0; ++kh; }
-        }
-    };
-
-    f32x4 acc[4][NI];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < NI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    const int nk = (K + BKE - 1) / BKE;
-    const int fr = lane & 15, fq = lane >> 4;
-    load_step();
-    for (int t = 0; t < nk; ++t) {
-        uint4* buf = lds[t & 1];
-#pragma unroll
-        for (int i = 0; i < 2; ++i) buf[(row0 + 64 * i) * 4 + slot] = ra[i];
-#pragma unroll
-        for (int j = 0; j < BCH; ++j) buf[(BM + row0 + 64 * j) * 4 + slot] = rb[j];
-        __syncthreads();
-        if (t + 1 < nk) load_step();
-        uint4 af[4], bf[NI];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            int r = wm * 64 + i * 16 + fr;
-            af[i] = buf[r * 4 + (fq ^ swz4(r))];
-        }
-#pragma unroll
-        for (int j = 0; j < NI; ++j) {
-            int r = wn * (BN / 2) + j * 16 + fr;
-            bf[j] = buf[(BM + r) * 4 + (fq ^ swz4(r))];
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < NI; ++j) mfma_step<T>(af[i], bf[j], acc[i][j]);
-    }
-
-    // ---- epilogue: bias + residual, direct stores ---------------------------------------
-#pragma unroll
-    for (int j = 0; j < NI; ++j) {
-        const int n = bn * BN + wn * (BN / 2) + j * 16 + fr;
-        if (n >= N) continue;
-        const float bv = bias ? bias[n] : 0.f;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int m = bm * BM + wm * 64 + i * 16 + fq * 4 + r;
-                if (m >= M) continue;
-                float v = acc[i][j][r] + bv;
-                if (residual) v += ldf<T>(residual + (long)m * g.res_ld + n);
-                if (out_f32) ((float*)out)[(long)m * g.out_ld + n] = v;
-                else stf<T>((T*)out + (long)m * g.out_ld + n, v);
-            }
-        }
-    }
-}
-
 // =========================================================================================
 // k_conv_gemm2: the same implicit GEMM with the staging done by LDS-DMA (global_load_lds_dwordx4,
 // no staging registers, no ds_write) into a 3-deep LDS ring, BK = 8 chunks (64 bf16 / 32 f32) per
@@ -213,7 +77,8 @@ template <typename T, int BM, int BN, int WM, int WN, int STAGES, int BKC>
 __global__ __launch_bounds__(WM* WN * 64) void k_conv_gemm2(
     NvaeConvGeom g, const T* __restrict__ src, const T* __restrict__ wT, int w_ld,
     const float* __restrict__ bias, const T* residual, void* out, int out_f32, int M, int K, int n_tiles,
-    int total_tiles, FastDiv fd_hw, FastDiv fd_w, const uint4* __restrict__ zeros) {
+    int total_tiles, FastDiv fd_hw, FastDiv fd_w, const uint4* __restrict__ zeros, float* stats,
+    int vec_epi) {
     constexpr int NT = WM * WN * 64;
     constexpr int VE = Tr<T>::VE;
     constexpr int BKE = BKC * VE;                  // K elements per ring step (BKC 16-B chunks per row)
@@ -223,6 +88,8 @@ __global__ __launch_bounds__(WM* WN * 64) void k_conv_gemm2(
     constexpr int NLOAD = ACH + BCH;
     static_assert(ACH >= 1 && BCH >= 1 && (NT / BKC) % 16 == 0, "tile/thread mismatch");
     static_assert(BKC == 8 || BKC == 16, "row width");
+    static_assert(STAGES * STAGE * 16 >= WM * WN * 16 * (BN / WN + 4) * 4, "epilogue staging must fit in the ring");
+    static_assert(STAGES * STAGE * 16 >= WM * BN * 2 * 4, "stats scratch must fit in the ring");
     static_assert(STAGES == 2 || STAGES == 3, "ring depth");
     __shared__ uint4 lds[STAGES * STAGE];
 
@@ -336,7 +203,92 @@ __global__ __launch_bounds__(WM* WN * 64) void k_conv_gemm2(
         cur = cur == STAGES - 1 ? 0 : cur + 1;
     }
 
-    // ---- epilogue: bias + residual, direct stores ---------------------------------------
+    // ---- epilogue -------------------------------------------------------------------------
+    // (a) optional BatchNorm statistics of the output tile, straight from the accumulators:
+    //     per column sum and sum of squares over the tile's valid rows -> stats[bm][2][N]
+    if (stats) {
+        __syncthreads();                                  // ring no longer read
+        float* red = (float*)lds;                         // [WM][BN][2]
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const int nl = wn * (BN / WN) + j * 16 + fr;
+            const int n = bn * BN + nl;
+            const float bv = (bias && n < N) ? bias[n] : 0.f;
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = bm * BM + wm * (BM / WM) + i * 16 + fq * 4 + r;
+                    const float v = m < M ? acc[i][j][r] + bv : 0.f;
+                    s1 += v; s2 += v * v;
+                }
+            s1 += __shfl_xor(s1, 16, 64); s1 += __shfl_xor(s1, 32, 64);
+            s2 += __shfl_xor(s2, 16, 64); s2 += __shfl_xor(s2, 32, 64);
+            if (fq == 0) { red[(wm * BN + nl) * 2] = s1; red[(wm * BN + nl) * 2 + 1] = s2; }
+        }
+        __syncthreads();
+        for (int nl = tid; nl < BN; nl += NT) {
+            const int n = bn * BN + nl;
+            if (n >= N) continue;
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int w = 0; w < WM; ++w) { s1 += red[(w * BN + nl) * 2]; s2 += red[(w * BN + nl) * 2 + 1]; }
+            stats[((long)bm * 2) * N + n] = s1;
+            stats[((long)bm * 2 + 1) * N + n] = s2;
+        }
+    }
+    // (b) output.  Vector path: each wave stages one 16-row slab of its tile in LDS (f32), then every
+    //     lane stores 8 consecutive columns of one row (16 B bf16 / 32 B f32) - whole-line writes
+    //     instead of the 2-byte column-strided stores the MFMA C layout gives directly.
+    constexpr int WCOLS = BN / WN;
+    constexpr int SROW = WCOLS + 4;                        // padded f32 row
+    constexpr int VPR = WCOLS / 8;                         // 8-column vectors per row
+    if (vec_epi) {
+        __syncthreads();
+        float* st = (float*)lds + wave * (16 * SROW);
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) st[(fq * 4 + r) * SROW + j * 16 + fr] = acc[i][j][r];
+            __syncthreads();
+            for (int v = lane; v < 16 * VPR; v += 64) {
+                const int row = v / VPR, c8 = v - row * VPR;
+                const int m = bm * BM + wm * (BM / WM) + i * 16 + row;
+                const int n0 = bn * BN + wn * WCOLS + c8 * 8;
+                if (m >= M || n0 >= N) continue;
+                float o[8];
+                const float4 lo = *(const float4*)(st + row * SROW + c8 * 8), hi = *(const float4*)(st + row * SROW + c8 * 8 + 4);
+                o[0] = lo.x; o[1] = lo.y; o[2] = lo.z; o[3] = lo.w; o[4] = hi.x; o[5] = hi.y; o[6] = hi.z; o[7] = hi.w;
+                if (n0 + 8 <= N) {
+                    if (bias) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) o[e] += bias[n0 + e];
+                    }
+                    if (residual) {
+                        float rr[8];
+                        V8<T>::ld(residual + (long)m * g.res_ld + n0, rr);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) o[e] += rr[e];
+                    }
+                    if (out_f32) V8<float>::st((float*)out + (long)m * g.out_ld + n0, o);
+                    else V8<T>::st((T*)out + (long)m * g.out_ld + n0, o);
+                } else {
+                    for (int e = 0; e < 8 && n0 + e < N; ++e) {
+                        float vv = o[e] + (bias ? bias[n0 + e] : 0.f);
+                        if (residual) vv += ldf<T>(residual + (long)m * g.res_ld + n0 + e);
+                        if (out_f32) ((float*)out)[(long)m * g.out_ld + n0 + e] = vv;
+                        else stf<T>((T*)out + (long)m * g.out_ld + n0 + e, vv);
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        return;
+    }
+    // scalar path (unaligned channel slices, e.g. SkipScaler's 10-channel outputs)
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
         const int n = bn * BN + wn * (BN / WN) + j * 16 + fr;
@@ -371,20 +323,34 @@ static int check_geom_mfma(const char* who, const NvaeConvGeom* g) {
     return NVAE_OK;
 }
 
+static int conv_gemm_bm(const NvaeConvGeom* g) {
+    // M-tile height the launcher will pick (must match launch_conv_gemm)
+    const int M = g->B * g->Hout * g->Wout, K = g->KH * g->KW * g->Cin, N = g->Cout;
+    const long big_tiles = (long)cdiv(M, 128) * cdiv(N, 128);
+    const long w192 = (long)cdiv(N, 192) * 192, w128 = (long)cdiv(N, 128) * 128, w64 = (long)cdiv(N, 64) * 64;
+    if ((long)cdiv(M, 256) * cdiv(N, 192) >= 224 && w192 <= w128 && w192 <= w64 && K >= 1024) return 256;
+    if (big_tiles >= 192) return 128;
+    return 64;
+}
+
 template <typename T>
 static int launch_conv_gemm(const NvaeConvGeom* g, const void* src, const void* wT, int w_ld,
                             const float* bias, const void* residual, void* out, int out_f32,
-                            hipStream_t s) {
+                            float* stats, hipStream_t s) {
     const int M = g->B * g->Hout * g->Wout, K = g->KH * g->KW * g->Cin, N = g->Cout;
     FastDiv fd_hw = make_fastdiv((unsigned)(g->Hout * g->Wout)), fd_w = make_fastdiv((unsigned)g->Wout);
     uint4* zeros = nullptr;
     (void)hipGetSymbolAddress((void**)&zeros, HIP_SYMBOL(g_zero16));
+    // 16-B row-contiguous stores need aligned rows; otherwise the scalar epilogue
+    const int vo = out_f32 ? 4 : (int)(16 / sizeof(T));
+    const int vec_epi = (g->out_ld % vo == 0) && aligned16(out) &&
+                        (!residual || (g->res_ld % (int)(16 / sizeof(T)) == 0 && aligned16(residual)));
 #define LAUNCH2(BM_, BN_, WM_, WN_, ST_, BKC_)                                                          \
     {                                                                                                   \
         int mt = cdiv(M, BM_), nt = cdiv(N, BN_);                                                       \
         hipLaunchKernelGGL((k_conv_gemm2<T, BM_, BN_, WM_, WN_, ST_, BKC_>), mt * nt, WM_ * WN_ * 64, 0, s, *g, \
                            (const T*)src, (const T*)wT, w_ld, bias, (const T*)residual, out, out_f32, M, \
-                           K, nt, mt * nt, fd_hw, fd_w, zeros);                                         \
+                           K, nt, mt * nt, fd_hw, fd_w, zeros, stats, vec_epi);                         \
     }
     // Large problems: 128-row tiles, 8 waves; N tile with the least padding (ties -> larger).
     // Small problems (few tiles): 64 x 64 tiles, 4 waves, so that the grid covers the chip.
@@ -407,9 +373,14 @@ static int launch_conv_gemm(const NvaeConvGeom* g, const void* src, const void* 
     return 0;
 }
 
+extern "C" int nvae_conv_gemm_mtiles(const NvaeConvGeom* g) {
+    if (!g) return 0;
+    return cdiv((long)g->B * g->Hout * g->Wout, conv_gemm_bm(g));
+}
+
 extern "C" int nvae_conv_gemm(int dtype, const NvaeConvGeom* g, const void* src, const void* wT, int w_ld,
                               const float* bias, const void* residual, void* out, int out_f32,
-                              void* stream) {
+                              float* stats, void* stream) {
     if (int e = check_geom_mfma("conv_gemm", g)) return e;
     NVAE_REQUIRE(src && wT && out, "conv_gemm: NULL pointer");
     const int ve = (dtype == NVAE_BF16) ? 8 : 4;
@@ -418,229 +389,9 @@ extern "C" int nvae_conv_gemm(int dtype, const NvaeConvGeom* g, const void* src,
     NVAE_REQUIRE(w_ld >= g->KH * g->KW * g->Cin, "conv_gemm: w_ld too small");
     NVAE_REQUIRE(aligned16(src) && aligned16(wT), "conv_gemm: src/wT must be 16-B aligned");
     NVAE_REQUIRE(!residual || g->res_ld >= g->Cout, "conv_gemm: res_ld too small");
-    DISPATCH_T(dtype, launch_conv_gemm<T>(g, src, wT, w_ld, bias, residual, out, out_f32, (hipStream_t)stream);)
+    DISPATCH_T(dtype, launch_conv_gemm<T>(g, src, wT, w_ld, bias, residual, out, out_f32, stats, (hipStream_t)stream);)
     NVAE_LAUNCH_CHECK("conv_gemm");
     return NVAE_OK;
-}
-
-// =========================================================================================
-// weight gradient
-// =========================================================================================
-// LDS image: [RS pixels][COLS channels]; byte offset of 16-B chunk `cc` of pixel row `m`.
-template <typename T, int COLS>
-__device__ __forceinline__ int img_off(int m, int cc) {
-    if constexpr (sizeof(T) == 2) {
-        // 32-B segments (16 bf16) XOR-swizzled so the 8 rows a half-wave transposes hit 8 bank octets
-        constexpr int ROWB = COLS * 2;
-        int seg = cc >> 1;
-        int s = (COLS >= 128) ? ((m & 3) | (((m >> 3) & 1) << 2)) : (((m >> 1) & 1) | (((m >> 3) & 1) << 1));
-        return m * ROWB + ((seg ^ s) << 5) + ((cc & 1) << 4);
-    } else {
-        constexpr int ROWB = COLS * 4;
-        int seg = cc >> 2;   // 64-B segments (16 floats)
-        return m * ROWB + ((seg ^ (m & 1)) << 6) + ((cc & 3) << 4);
-    }
-}
-
-template <typename T, int BNT>
-__global__ __launch_bounds__(256, 2) void k_conv_wgrad(NvaeConvGeom g, const T* __restrict__ x,
-                                                       const T* __restrict__ dy, float* dw, int dw_ld,
-                                                       float* db, int M, int K, int n_tiles,
-                                                       int m_per_split, FastDiv fd_hw, FastDiv fd_w) {
-    constexpr int BKT = 128;
-    constexpr int VE = Tr<T>::VE;
-    constexpr int RS = 4 * VE;                 // pixels per reduction step (32 bf16 / 16 f32)
-    constexpr int CPR_A = BKT / VE;            // chunks per A-image row
-    constexpr int CPR_B = BNT / VE;
-    constexpr int A_CH = RS * CPR_A / 256;     // = 2
-    constexpr int B_CH = RS * CPR_B / 256;     // 128 -> 2, 64 -> 1
-    constexpr int NI = BNT / 32;
-    constexpr int A_BYTES = RS * BKT * (int)sizeof(T);
-    constexpr int B_BYTES = RS * BNT * (int)sizeof(T);
-    __shared__ __attribute__((aligned(16))) unsigned char lds[2][A_BYTES + B_BYTES];
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wk = wave >> 1, wn = wave & 1;
-    const int kt = blockIdx.x / n_tiles, nt = blockIdx.x - kt * n_tiles;
-    const int k0 = kt * BKT, n0 = nt * BNT;
-    const int N = g.Cout;
-    const int m_begin = blockIdx.y * m_per_split;
-    int m_end = m_begin + m_per_split;
-    if (m_end > M) m_end = M;
-
-    // A-side: fixed k chunk per thread
-    const int a_cc = tid % CPR_A, a_row0 = tid / CPR_A;
-    const int kcol = k0 + a_cc * VE;
-    const bool kval = kcol < K;
-    int tap = kval ? kcol / g.Cin : 0;
-    const int ci = kval ? kcol - tap * g.Cin : 0;
-    const int kh = tap / g.KW, kw = tap - kh * g.KW;
-    const int hlim = g.Hin * g.div, wlim = g.Win * g.div;
-    // B-side
-    const int b_cc = tid % CPR_B, b_row0 = tid / CPR_B;
-    const int ncol = n0 + b_cc * VE;
-    const bool nval = ncol < N;
-
-    // bias gradient db[n] = sum_m dy[m, n]: folded into the k-tile-0 workgroups, which already
-    // stream every dy element of their n range through registers
-    const bool do_bias = (db != nullptr) && (kt == 0);
-    float bsum[VE];
-#pragma unroll
-    for (int j = 0; j < VE; ++j) bsum[j] = 0.f;
-
-    uint4 ra[A_CH], rb[B_CH];
-    auto load_step = [&](int mbase) {
-#pragma unroll
-        for (int i = 0; i < A_CH; ++i) {
-            int m = mbase + a_row0 + i * (256 / CPR_A);
-            ra[i] = make_uint4(0, 0, 0, 0);
-            if (kval && m < m_end) {
-                unsigned b = fdiv((unsigned)m, fd_hw);
-                unsigned rem = (unsigned)m - b * fd_hw.d;
-                unsigned ho = fdiv(rem, fd_w);
-                unsigned wo = rem - ho * fd_w.d;
-                int hc = (int)ho * g.stride - g.pad_t + kh, wc = (int)wo * g.stride - g.pad_l + kw;
-                bool ok = hc >= 0 && hc < hlim && wc >= 0 && wc < wlim;
-                int hs = hc, ws = wc;
-                if (g.div != 1) {
-                    hs = hc / g.div; ws = wc / g.div;
-                    if (g.exact) ok = ok && (hs * g.div == hc) && (ws * g.div == wc);
-                }
-                if (ok) ra[i] = *(const uint4*)(x + ((long)b * g.Hin * g.Win + (long)hs * g.Win + ws) * g.in_ld + ci);
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < B_CH; ++i) {
-            int m = mbase + b_row0 + i * (256 / CPR_B);
-            rb[i] = make_uint4(0, 0, 0, 0);
-            if (nval && m < m_end) rb[i] = *(const uint4*)(dy + (long)m * g.out_ld + ncol);
-            if (do_bias) {
-                if constexpr (sizeof(T) == 2) {
-                    bsum[0] += __uint_as_float(rb[i].x << 16); bsum[1] += __uint_as_float(rb[i].x & 0xffff0000u);
-                    bsum[2] += __uint_as_float(rb[i].y << 16); bsum[3] += __uint_as_float(rb[i].y & 0xffff0000u);
-                    bsum[4] += __uint_as_float(rb[i].z << 16); bsum[5] += __uint_as_float(rb[i].z & 0xffff0000u);
-                    bsum[6] += __uint_as_float(rb[i].w << 16); bsum[7] += __uint_as_float(rb[i].w & 0xffff0000u);
-                } else {
-                    bsum[0] += __uint_as_float(rb[i].x); bsum[1] += __uint_as_float(rb[i].y);
-                    bsum[2] += __uint_as_float(rb[i].z); bsum[3] += __uint_as_float(rb[i].w);
-                }
-            }
-        }
-    };
-
-    f32x4 acc[4][NI];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < NI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    const int fr = lane & 15, fq = lane >> 4;
-    const int nsteps = (m_end - m_begin + RS - 1) / RS;
-    if (nsteps > 0) load_step(m_begin);
-    for (int t = 0; t < nsteps; ++t) {
-        unsigned char* bufA = lds[t & 1];
-        unsigned char* bufB = bufA + A_BYTES;
-#pragma unroll
-        for (int i = 0; i < A_CH; ++i)
-            *(uint4*)(bufA + img_off<T, BKT>(a_row0 + i * (256 / CPR_A), a_cc)) = ra[i];
-#pragma unroll
-        for (int i = 0; i < B_CH; ++i)
-            *(uint4*)(bufB + img_off<T, BNT>(b_row0 + i * (256 / CPR_B), b_cc)) = rb[i];
-        __syncthreads();
-        if (t + 1 < nsteps) load_step(m_begin + (t + 1) * RS);
-
-        if constexpr (sizeof(T) == 2) {
-            // operand (lane: k-row/col fr, pixels 8*fq .. 8*fq+7) = two transposed 4x16 reads
-            const int q = fr >> 2, p = fr & 3;
-            const int mr = 8 * fq + q;
-            bf16x8 af[4], bfr[NI];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int seg = wk * 4 + i;
-                int s0 = (mr & 3) | (((mr >> 3) & 1) << 2);
-                int mr1 = mr + 4;
-                int s1 = (mr1 & 3) | (((mr1 >> 3) & 1) << 2);
-                auto lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-                    (__attribute__((address_space(3))) bf16x4*)(bufA + mr * (BKT * 2) + ((seg ^ s0) << 5) + p * 8));
-                auto hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-                    (__attribute__((address_space(3))) bf16x4*)(bufA + mr1 * (BKT * 2) + ((seg ^ s1) << 5) + p * 8));
-                af[i] = (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-            }
-#pragma unroll
-            for (int j = 0; j < NI; ++j) {
-                const int seg = wn * (BNT / 32) + j;
-                int mr1 = mr + 4;
-                int s0, s1;
-                if (BNT >= 128) {
-                    s0 = (mr & 3) | (((mr >> 3) & 1) << 2);
-                    s1 = (mr1 & 3) | (((mr1 >> 3) & 1) << 2);
-                } else {
-                    s0 = ((mr >> 1) & 1) | (((mr >> 3) & 1) << 1);
-                    s1 = ((mr1 >> 1) & 1) | (((mr1 >> 3) & 1) << 1);
-                }
-                auto lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-                    (__attribute__((address_space(3))) bf16x4*)(bufB + mr * (BNT * 2) + ((seg ^ s0) << 5) + p * 8));
-                auto hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-                    (__attribute__((address_space(3))) bf16x4*)(bufB + mr1 * (BNT * 2) + ((seg ^ s1) << 5) + p * 8));
-                bfr[j] = (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < NI; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
-        } else {
-            // f32: 16x16x4, lane (fr, fq) supplies A[k-row fr][pixel 4*s + fq], B[pixel 4*s + fq][n fr]
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const int m = 4 * s + fq;
-                float af[4], bfr[NI];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    int col = wk * 64 + i * 16 + fr;
-                    af[i] = *(const float*)(bufA + m * (BKT * 4) + (((col >> 4) ^ (m & 1)) << 6) + ((col & 15) << 2));
-                }
-#pragma unroll
-                for (int j = 0; j < NI; ++j) {
-                    int col = wn * (BNT / 2) + j * 16 + fr;
-                    bfr[j] = *(const float*)(bufB + m * (BNT * 4) + (((col >> 4) ^ (m & 1)) << 6) + ((col & 15) << 2));
-                }
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int j = 0; j < NI; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bfr[j], acc[i][j], 0, 0, 0);
-            }
-        }
-    }
-
-    // ---- epilogue: f32 atomics into the flat gradient buffer ------------------------------
-    if (do_bias) {
-        __syncthreads();
-        float* red = (float*)lds[0];                 // [256 / CPR_B rows][CPR_B][VE]
-#pragma unroll
-        for (int j = 0; j < VE; ++j) red[tid * VE + j] = bsum[j];
-        __syncthreads();
-        if (tid < CPR_B * VE) {
-            const int cc = tid / VE, j = tid - cc * VE;
-            float a = 0.f;
-            for (int r = 0; r < 256 / CPR_B; ++r) a += red[(r * CPR_B + cc) * VE + j];
-            const int n = n0 + cc * VE + j;
-            if (n < N) atomicAdd(db + n, a);
-        }
-    }
-#pragma unroll
-    for (int j = 0; j < NI; ++j) {
-        const int n = n0 + wn * (BNT / 2) + j * 16 + fr;
-        if (n >= N) continue;
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int k = k0 + wk * 64 + i * 16 + fq * 4 + r;
-                if (k < K) atomicAdd(dw + (long)k * dw_ld + n, acc[i][j][r]);
-            }
-    }
 }
 
 // =========================================================================================

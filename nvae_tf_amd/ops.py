@@ -21,12 +21,13 @@ def same_pad(in_size: int, k: int, s: int) -> Tuple[int, int]:
 
 class Var:
     """An NHWC activation and (lazily) its gradient."""
-    __slots__ = ("t", "g", "needs_grad")
+    __slots__ = ("t", "g", "needs_grad", "stats")
 
     def __init__(self, t: torch.Tensor, needs_grad: bool = True):
         self.t = t
         self.g: Optional[torch.Tensor] = None
         self.needs_grad = needs_grad
+        self.stats = None   # (slab [S,2,C] f32, S): BN statistics partials emitted by the producing conv
 
     @property
     def shape(self):
@@ -112,7 +113,7 @@ def _geom(B, Hin, Win, Cin, Hout, Wout, Cout, KH, KW, stride, pad_t, pad_l, div,
 def conv2d(ctx: Ctx, x: Var, conv, *, stride: int = 1, up: int = 1, pad: Optional[Tuple[int, int]] = None,
            out_hw: Optional[Tuple[int, int]] = None, c_off: int = 0, cin: Optional[int] = None,
            bias: bool = True, out: Optional[Var] = None, out_coff: int = 0, accumulate: bool = False,
-           residual: Optional[Var] = None, out_f32: bool = False) -> Var:
+           residual: Optional[Var] = None, out_f32: bool = False, want_stats: bool = False) -> Var:
     """Conv2D(padding='same') (+ folded nearest upsample, + residual add).  `conv` is a
     params.ConvParam.  c_off/cin select a row slice of a 1x1 kernel (concat-free
     DecoderSampleCombiner, decoder.py:115-117); out/out_coff write a channel slice of an existing
@@ -148,8 +149,14 @@ def conv2d(ctx: Ctx, x: Var, conv, *, stride: int = 1, up: int = 1, pad: Optiona
     fwd_mfma = cin % ve == 0 and Cx % ve == 0 and c_off % ve == 0 and conv.wf_off >= 0
     if fwd_mfma:
         wT = ptr(ps.wcopies) + (conv.wf_off + c_off) * ps.wcopies.element_size()
+        slab = None
+        if want_stats and ctx.training and not accumulate and out_coff == 0 and Cy == cout:
+            # the conv's epilogue emits the BatchNorm statistics of its output (consumed by bn_act)
+            S = L.load().nvae_conv_gemm_mtiles(C.byref(g))
+            slab = ctx.empty((S, 2, cout), torch.float32)
+            out.stats = (slab, S)
         call("nvae_conv_gemm", ctx.dt, C.byref(g), ptr(x.t), wT, conv.wf_ld, bias_ptr, res_ptr, out_ptr,
-             int(out_f32))
+             int(out_f32), ptr(slab))
     else:
         w = ptr(ps.view(conv.w)) + c_off * cout * 4
         call("nvae_conv_direct", ctx.dt, C.byref(g), ptr(x.t), w, conv.cin * cout, cout, 1, 0, bias_ptr,
@@ -193,7 +200,7 @@ def conv2d(ctx: Ctx, x: Var, conv, *, stride: int = 1, up: int = 1, pad: Optiona
                 if d_mfma:
                     wD = ptr(ps.wcopies) + (conv.wd_off + c_off * conv.wd_ld) * ps.wcopies.element_size()
                     call("nvae_conv_gemm", ctx.dt, C.byref(gd), dy_ptr, wD, conv.wd_ld, None, resid,
-                         ptr(dst), 0)
+                         ptr(dst), 0, None)
                 else:
                     w = ptr(ps.view(conv.w)) + c_off * cout * 4
                     call("nvae_conv_direct", ctx.dt, C.byref(gd), dy_ptr, w, conv.cin * cout, 1, cout, 1,
@@ -237,7 +244,11 @@ def bn_act(ctx: Ctx, x: Var, bn, act: int = L.ACT_NONE) -> Var:
     gamma, beta = ptr(ps.view(bn.gamma)), ptr(ps.view(bn.beta))
     rm, rv = ptr(ps.sview(bn.rm)), ptr(ps.sview(bn.rv))
     S = L.load().nvae_reduce_splits(rows, Cc)
-    if ctx.training:
+    if ctx.training and x.stats is not None:
+        slab, Sx = x.stats
+        call("nvae_bn_finalize_s", ptr(slab), Sx, rows, Cc, gamma, beta, rm, rv, BN_MOMENTUM, BN_EPS, scale,
+             shift, mean, invstd)
+    elif ctx.training:
         partials = ctx.empty((S, 2, Cc), torch.float32)
         call("nvae_bn_stats", ctx.dt, ptr(x.t), rows, Cc, ptr(partials))
         call("nvae_bn_finalize", ptr(partials), rows, Cc, gamma, beta, rm, rv, BN_MOMENTUM, BN_EPS, scale,

@@ -16,7 +16,7 @@ class ConvBNSwish:
         self.bn = ps.bn(name_bn, n_channels)
 
     def __call__(self, ctx: Ctx, x: Var) -> Var:
-        x = ops.conv2d(ctx, x, self.conv, bias=False)
+        x = ops.conv2d(ctx, x, self.conv, bias=False, want_stats=True)
         return ops.bn_act(ctx, x, self.bn, L.ACT_SWISH)
 
 
@@ -26,6 +26,8 @@ class PostprocessNode:
     def __init__(self, ps, name: str, in_channels: int, n_channels: int, scale_factor: int, upscale: bool,
                  expansion_ratio: int = 6):
         self.up = Rescaler(ps, name + ".up", in_channels, n_channels, scale_factor, RescaleType.UP) if upscale else None
+        if self.up is not None:
+            self.up.feeds_bn = True        # node path: Rescaler -> bn0
         self.bn0 = ps.bn(name + ".bn0", n_channels)
         hidden = n_channels * expansion_ratio
         self.cbs1 = ConvBNSwish(ps, name + ".conv1", name + ".bn1", n_channels, hidden, 1)
@@ -40,7 +42,7 @@ class PostprocessNode:
         x = ops.bn_act(ctx, x, self.bn0)
         x = self.cbs1(ctx, x)
         x = self.cbs5(ctx, x)
-        x = ops.conv2d(ctx, x, self.conv3, bias=False)
+        x = ops.conv2d(ctx, x, self.conv3, bias=False, want_stats=True)
         x = ops.bn_act(ctx, x, self.bn3)
         return self.se(ctx, x, skip, 1.0, 0.1)      # skip + 0.1 * sequence, postprocess.py:58
 

@@ -466,4 +466,4 @@ def test_bad_arguments_fail_loudly(lib, dev):
         L.call("nvae_unary_fwd", L.F32, L.OP_ELU, L.ptr(x), L.ptr(x), 12, 0.0, 0.0)
     g = L.ConvGeom(1, 4, 4, 3, 4, 4, 8, 3, 3, 1, 1, 1, 1, 0, 3, 8, 8)
     with pytest.raises(RuntimeError, match="conv_direct"):
-        L.call("nvae_conv_gemm", L.BF16, C.byref(g), L.ptr(x), L.ptr(x), 32, None, None, L.ptr(x), 0)
+        L.call("nvae_conv_gemm", L.BF16, C.byref(g), L.ptr(x), L.ptr(x), 32, None, None, L.ptr(x), 0, None)
