@@ -4,6 +4,22 @@
 // write of the tensor.  Weights are the f32 masters [5,5,C] (25*C*4 B, L2-resident).
 #include "common.h"
 
+// two adjacent channels in one LDS / global access
+template <typename T> __device__ __forceinline__ void ld2(const T* p, float& a, float& b);
+template <> __device__ __forceinline__ void ld2<bf16>(const bf16* p, float& a, float& b) {
+    const unsigned v = *(const unsigned*)p;
+    a = __uint_as_float(v << 16); b = __uint_as_float(v & 0xffff0000u);
+}
+template <> __device__ __forceinline__ void ld2<float>(const float* p, float& a, float& b) {
+    const float2 v = *(const float2*)p;
+    a = v.x; b = v.y;
+}
+template <typename T> __device__ __forceinline__ void st2(T* p, float a, float b);
+template <> __device__ __forceinline__ void st2<bf16>(bf16* p, float a, float b) {
+    *(unsigned*)p = (unsigned)f2bf(a) | ((unsigned)f2bf(b) << 16);
+}
+template <> __device__ __forceinline__ void st2<float>(float* p, float a, float b) { *(float2*)p = make_float2(a, b); }
+
 template <typename T>
 __global__ void k_dwconv5(const T* __restrict__ x, const float* __restrict__ w,
                           const float* __restrict__ bias, T* y, int H, int W, int C8, long n8, int flip,
@@ -41,10 +57,83 @@ __global__ void k_dwconv5(const T* __restrict__ x, const float* __restrict__ w,
     }
 }
 
+// LDS-resident variant for H*W <= 64 (the 4x4 / 8x8 towers): a workgroup owns 128 channels of a chunk
+// of images; the [HW][128] input slab is staged in LDS once per image, each thread keeps the 25 taps of
+// its two channels in registers and produces the outputs of every 4th pixel.
+template <typename T>
+__global__ __launch_bounds__(256) void k_dwconv5_lds(const T* __restrict__ x, const float* __restrict__ w,
+                                                     const float* __restrict__ bias, T* y, int B, int H, int W,
+                                                     int C, int flip, int acc, int imgs_per_block) {
+    constexpr int CS = 128;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    T* sx = (T*)smem;
+    const int HW = H * W;
+    const int c_base = blockIdx.x * CS;
+    const int cp = threadIdx.x & 63, pg = threadIdx.x >> 6;
+    const int c = c_base + 2 * cp;
+    const bool cval = c < C;
+    float wr[25][2];
+#pragma unroll
+    for (int t = 0; t < 25; ++t) {
+        const int tap = flip ? 24 - t : t;
+        wr[t][0] = cval ? w[(long)tap * C + c] : 0.f;
+        wr[t][1] = cval ? w[(long)tap * C + c + 1] : 0.f;
+    }
+    const float b0 = (bias && cval) ? bias[c] : 0.f, b1 = (bias && cval) ? bias[c + 1] : 0.f;
+    constexpr int VE = 16 / (int)sizeof(T);
+    const int chunks_per_row = CS / VE, nchunks = HW * chunks_per_row;
+    const int img0 = blockIdx.y * imgs_per_block;
+    int img1 = img0 + imgs_per_block;
+    if (img1 > B) img1 = B;
+    for (int b = img0; b < img1; ++b) {
+        __syncthreads();
+        for (int q = threadIdx.x; q < nchunks; q += 256) {
+            int p = q / chunks_per_row, cc = (q - p * chunks_per_row) * VE;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (c_base + cc < C) v = *(const uint4*)(x + ((long)b * HW + p) * C + c_base + cc);
+            *(uint4*)(sx + p * CS + cc) = v;
+        }
+        __syncthreads();
+        if (!cval) continue;
+        for (int p = pg; p < HW; p += 4) {
+            const int h = p / W, wv = p - h * W;
+            T* yp = y + ((long)b * HW + p) * C + c;
+            float a0 = b0, a1 = b1;
+            if (acc) ld2<T>(yp, a0, a1);
+#pragma unroll
+            for (int kh = 0; kh < 5; ++kh) {
+                const int hi = h + kh - 2;
+                if (hi < 0 || hi >= H) continue;
+#pragma unroll
+                for (int kw = 0; kw < 5; ++kw) {
+                    const int wi = wv + kw - 2;
+                    if (wi < 0 || wi >= W) continue;
+                    float x0, x1;
+                    ld2<T>(sx + (hi * W + wi) * CS + 2 * cp, x0, x1);
+                    a0 += x0 * wr[kh * 5 + kw][0];
+                    a1 += x1 * wr[kh * 5 + kw][1];
+                }
+            }
+            st2<T>(yp, a0, a1);
+        }
+    }
+}
+
 extern "C" int nvae_dwconv5(int dtype, const void* x, const float* w, const float* bias, void* y, int B,
                             int H, int W, int C, int flip, int accumulate, void* stream) {
     NVAE_REQUIRE(B > 0 && H > 0 && W > 0 && C >= 8 && C % 8 == 0, "dwconv5: bad shape");
     NVAE_REQUIRE(aligned16(x) && aligned16(y) && aligned16(w), "dwconv5: alignment");
+    if (H * W <= 64) {
+        const int strips = cdiv(C, 128);
+        int want = 1024 / strips;
+        if (want < 1) want = 1;
+        int ipb = cdiv(B, want);
+        if (ipb < 1) ipb = 1;
+        dim3 grid(strips, cdiv(B, ipb));
+        DISPATCH_T(dtype, hipLaunchKernelGGL((k_dwconv5_lds<T>), grid, 256, (size_t)H * W * 128 * sizeof(T), (hipStream_t)stream, (const T*)x, w, bias, (T*)y, B, H, W, C, flip, accumulate, ipb);)
+        NVAE_LAUNCH_CHECK("dwconv5_lds");
+        return NVAE_OK;
+    }
     long n8 = (long)B * H * W * (C / 8);
     long g = (n8 + 255) / 256;
     if (g > 4096) g = 4096;
@@ -131,7 +220,8 @@ __global__ __launch_bounds__(256) void k_dwconv5_wgrad_lds(const T* __restrict__
         __syncthreads();
         for (int p = 0; p < HW; ++p) {
             const int h = p / W, wv = p - h * W;
-            const float g0 = ldf<T>(sdy + p * CS + 2 * cp), g1 = ldf<T>(sdy + p * CS + 2 * cp + 1);
+            float g0, g1;
+            ld2<T>(sdy + p * CS + 2 * cp, g0, g1);
             if (tg == 0) { ab0 += g0; ab1 += g1; }
 #pragma unroll
             for (int t = 0; t < 7; ++t) {
@@ -140,9 +230,10 @@ __global__ __launch_bounds__(256) void k_dwconv5_wgrad_lds(const T* __restrict__
                 const int kh = tap / 5, kw = tap - kh * 5;
                 const int hi = h + kh - 2, wi = wv + kw - 2;
                 if (hi < 0 || hi >= H || wi < 0 || wi >= W) continue;
-                const T* xp = sx + (hi * W + wi) * CS + 2 * cp;
-                acc[t][0] += g0 * ldf<T>(xp);
-                acc[t][1] += g1 * ldf<T>(xp + 1);
+                float x0, x1;
+                ld2<T>(sx + (hi * W + wi) * CS + 2 * cp, x0, x1);
+                acc[t][0] += g0 * x0;
+                acc[t][1] += g1 * x1;
             }
         }
     }
