@@ -84,6 +84,8 @@ class NVAE:
         self.rng_counter = torch.zeros(1, dtype=torch.int64, device=dev)
         self._buf: Dict[int, Dict[str, torch.Tensor]] = {}
         self._plan = None
+        self.overlap_wgrad = True   # weight-gradient kernels run on a side stream, joined before Adamax
+        self._side = None
 
     # ------------------------------------------------------------------ helpers
     def n_trainable(self) -> int:
@@ -225,7 +227,10 @@ class NVAE:
         buf = self._buffers(B)
         ps.begin_step()
         ps.prepare_weights(spectral_norm=spectral_norm)
-        ctx = Ctx(ps, self.dtype, training=True, record=True)
+        if self.overlap_wgrad and self._side is None and self.device.type == "cuda":
+            self._side = torch.cuda.Stream(device=self.device)
+        ctx = Ctx(ps, self.dtype, training=True, record=True,
+                  side_stream=self._side if self.overlap_wgrad else None)
         self._bn_loss = ctx.zeros_f32(1)
         nb = len(ps.bn_loss_layers)
         if nb:

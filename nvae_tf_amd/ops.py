@@ -4,6 +4,7 @@ device buffers only.  Gradients accumulate through the kernels' own `accumulate`
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Callable, List, Optional, Tuple
 
 import torch
@@ -37,8 +38,15 @@ class Var:
 class Ctx:
     """Per-step execution context: dtype, mode, tape, and the per-step zeroed f32 scratch pool."""
 
-    def __init__(self, ps, dtype: torch.dtype, training: bool, record: bool, zero_pool_floats: int = 0):
+    def __init__(self, ps, dtype: torch.dtype, training: bool, record: bool, side_stream=None):
         self.ps = ps
+        # Weight-gradient kernels do not feed the backward critical path (dgrad -> BN -> dgrad ...)
+        # and most of them fill only a fraction of the chip; with a side stream they are forked off
+        # the main stream (also inside hipGraph capture) and joined at the end of backward().
+        self.side = side_stream
+        self.keep: List[torch.Tensor] = []
+        self.deferred: List[Callable[[], None]] = []
+        self.flush_every = int(os.environ.get("NVAE_WGRAD_FLUSH", "64"))
         self.dtype = dtype
         self.dt = L.dtype_code(dtype)
         self.ve = 8 if dtype == torch.bfloat16 else 4
@@ -69,9 +77,35 @@ class Ctx:
             return v.g, 0
         return v.g, 1
 
+    def side_launch(self, fn: Callable[[], None], *keep):
+        """Enqueue independent gradient work after everything issued so far, off the main stream.
+        `keep` are temporaries that must outlive the side-stream kernels (held until the join)."""
+        if self.side is None:
+            fn()
+            return
+        # Deferred: cross-stream edges are not free in a hipGraph, so the work is forked in batches
+        # (its inputs are kept alive; nothing on the main stream overwrites them).
+        self.deferred.append(fn)
+        self.keep.extend(t for t in keep if t is not None)
+        if len(self.deferred) >= self.flush_every:
+            self.flush_side()
+
+    def flush_side(self):
+        if not self.deferred:
+            return
+        self.side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self.side):
+            for fn in self.deferred:
+                fn()
+        self.deferred.clear()
+
     def backward(self):
         for fn in reversed(self.tape):
             fn()
+        if self.side is not None:
+            self.flush_side()
+            torch.cuda.current_stream().wait_stream(self.side)   # join before the optimizer / all-reduce
+        self.keep.clear()
         self.tape.clear()
 
 
@@ -177,9 +211,11 @@ def conv2d(ctx: Ctx, x: Var, conv, *, stride: int = 1, up: int = 1, pad: Optiona
             if w_mfma:
                 need = L.load().nvae_conv_wgrad_scratch(ctx.dt, C.byref(gw))
                 scratch = ctx.empty((need,), torch.float32) if need else None
-                call("nvae_conv_wgrad", ctx.dt, C.byref(gw), ptr(x.t), dy_ptr, dw, cout, db, ptr(scratch), need)
+                ctx.side_launch(lambda: call("nvae_conv_wgrad", ctx.dt, C.byref(gw), ptr(x.t), dy_ptr, dw, cout, db,
+                                             ptr(scratch), need), scratch, dy)
             else:
-                call("nvae_conv_direct_wgrad", ctx.dt, C.byref(gw), ptr(x.t), dy_ptr, dw, cout, db)
+                ctx.side_launch(lambda: call("nvae_conv_direct_wgrad", ctx.dt, C.byref(gw), ptr(x.t), dy_ptr, dw,
+                                             cout, db), dy)
             # ---- residual
             if residual is not None and residual.needs_grad:
                 add_grad(ctx, residual, dy)
@@ -220,8 +256,8 @@ def dwconv5(ctx: Ctx, x: Var, dw) -> Var:
     call("nvae_dwconv5", ctx.dt, ptr(x.t), ptr(ps.view(dw.w)), ptr(ps.view(dw.b)), ptr(y.t), B, H, W, Cc, 0, 0)
     if ctx.record:
         def bwd():
-            call("nvae_dwconv5_wgrad", ctx.dt, ptr(x.t), ptr(y.g), ptr(ps.grads) + dw.w.off * 4,
-                 ptr(ps.grads) + dw.b.off * 4, B, H, W, Cc)
+            ctx.side_launch(lambda: call("nvae_dwconv5_wgrad", ctx.dt, ptr(x.t), ptr(y.g), ptr(ps.grads) + dw.w.off * 4,
+                                         ptr(ps.grads) + dw.b.off * 4, B, H, W, Cc), y.g)
             g, acc = ctx.grad_of(x)
             call("nvae_dwconv5", ctx.dt, ptr(y.g), ptr(ps.view(dw.w)), None, ptr(g), B, H, W, Cc, 1, acc)
         ctx.tape.append(bwd)
