@@ -67,7 +67,7 @@ typedef struct NvaeConvGeom {
 /* stats (f32, may be NULL): [nvae_conv_gemm_mtiles(g)][2][Cout] per-M-tile column sums and sums of
  * squares of the output (bias included) - the BatchNorm statistics slab of the layer that follows,
  * consumed by nvae_bn_finalize_s.                                                                */
-int nvae_conv_gemm_mtiles(const NvaeConvGeom* g);
+int nvae_conv_gemm_mtiles(int dtype, const NvaeConvGeom* g);
 int nvae_conv_gemm(int dtype, const NvaeConvGeom* g, const void* src, const void* wT, int w_ld,
                    const float* bias, const void* residual, void* out, int out_f32, float* stats,
                    void* stream);

@@ -101,7 +101,7 @@ def load():
     lib.nvae_reduce_splits.restype = C.c_int
     lib.nvae_reduce_splits.argtypes = [_l, _i]
     lib.nvae_conv_gemm_mtiles.restype = C.c_int
-    lib.nvae_conv_gemm_mtiles.argtypes = [_G]
+    lib.nvae_conv_gemm_mtiles.argtypes = [_i, _G]
     lib.nvae_conv_wgrad_scratch.restype = C.c_long
     lib.nvae_conv_wgrad_scratch.argtypes = [_i, _G]
     for name, sig in _SIGS.items():

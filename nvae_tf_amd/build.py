@@ -13,7 +13,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libnvae_hip.so")
 OBJ = os.path.join(HERE, "build")
 SOURCES = ["elementwise.hip", "bn_se.hip", "loss.hip", "dwconv.hip", "conv_direct.hip",
-           "conv_mfma.hip", "sn.hip"]
+           "conv_gemm.hip", "conv_wgrad.hip", "sn.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
 
 

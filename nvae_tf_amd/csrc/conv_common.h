@@ -1,0 +1,64 @@
+// Shared device helpers of the MFMA convolution kernels (conv_gemm.hip, conv_wgrad.hip).
+#pragma once
+#include "common.h"
+
+template <typename T> struct Tr;
+template <> struct Tr<bf16> { static constexpr int VE = 8; };
+template <> struct Tr<float> { static constexpr int VE = 4; };
+
+__device__ __forceinline__ int swz4(int row) { return (0x1320 >> (((row >> 2) & 3) * 4)) & 3; }
+
+// bijective XCD remap (cdna guide T1): consecutive logical tiles land on one XCD
+__device__ __forceinline__ int xcd_remap(int id, int n) {
+    int q = n >> 3, r = n & 7, x = id & 7, l = id >> 3;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + l;
+}
+
+template <typename T>
+__device__ __forceinline__ void mfma_step(const uint4& a, const uint4& b, f32x4& acc) {
+    if constexpr (sizeof(T) == 2) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a),
+                                                      __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
+    } else {
+        // the lane's 16-B chunk holds 4 consecutive k; A and B use the same k permutation
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.x), __uint_as_float(b.x), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.y), __uint_as_float(b.y), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.z), __uint_as_float(b.z), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.w), __uint_as_float(b.w), acc, 0, 0, 0);
+    }
+}
+
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+template <int N> __device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int BKC> __device__ __forceinline__ int swz_row(int row) {
+    return BKC == 8 ? ((row >> 1) & 7) : (row & 15);
+}
+
+
+// zero page for padded / out-of-range DMA lanes (one copy per translation unit)
+static __device__ uint4 g_zero16[1];
+static inline const uint4* zero_page() {
+    uint4* z = nullptr;
+    (void)hipGetSymbolAddress((void**)&z, HIP_SYMBOL(g_zero16));
+    return z;
+}
+
+static int check_geom_mfma(const char* who, const NvaeConvGeom* g) {
+    NVAE_REQUIRE(g, "%s: NULL geometry", who);
+    NVAE_REQUIRE(g->B > 0 && g->Hin > 0 && g->Win > 0 && g->Cin > 0 && g->Hout > 0 && g->Wout > 0 && g->Cout > 0,
+                 "%s: non-positive dimension", who);
+    NVAE_REQUIRE(g->KH > 0 && g->KW > 0 && g->KH <= 7 && g->KW <= 7 && g->stride >= 1 && g->div >= 1,
+                 "%s: bad kernel/stride/div", who);
+    NVAE_REQUIRE(g->in_ld >= g->Cin && g->out_ld >= g->Cout, "%s: leading dimensions too small", who);
+    NVAE_REQUIRE((long)g->B * g->Hout * g->Wout < (1L << 23) && (long)g->B * g->Hin * g->Win < (1L << 23),
+                 "%s: more than 2^23 pixels per call unsupported", who);
+    return NVAE_OK;
+}
+

@@ -1,0 +1,515 @@
+// MFMA implicit-GEMM convolutions for gfx950: forward / data-gradient (k_conv_gemm) and
+// weight-gradient (k_conv_wgrad).  bf16 inputs use v_mfma_f32_16x16x32_bf16, f32 inputs use the
+// exact v_mfma_f32_16x16x4_f32; both accumulate in f32 and share one C/D fragment map
+// (col = lane & 15, row = 4*(lane >> 4) + reg).
+//
+// k_conv_gemm:  C[M, N] = A[M, K] * B[K, N],  M = B*Hout*Wout, K = KH*KW*Cin, N = Cout.
+//   A is gathered on the fly from the NHWC source (TF-'same' padding, stride, nearest-upsample or
+//   gradient dilation are all folded into the gather, see NvaeConvGeom); B comes pre-transposed
+//   ([N][K], k contiguous) so both LDS tiles are [rows][4 x 16-B chunks] and every MFMA operand is
+//   one ds_read_b128.  The tile is 128 x BN x (4 chunks), 4 waves as 2 x 2, LDS double-buffered with
+//   one barrier per K-step; the global loads of step t+1 are in flight behind the MFMAs of step t.
+//   LDS chunk slots are XOR-swizzled (slot = chunk ^ f(row), f = {0,2,3,1}[(row>>2)&3]), which makes
+//   the 16x16x32 operand read conflict-free over the hardware's 16-lane ds_read_b128 groups.
+//   Workgroups are renumbered so that each XCD owns a contiguous range of tiles (the N-tiles of one
+//   M-tile, and neighbouring M-tiles, share gathered activations and weight panels through that L2).
+//
+// k_conv_wgrad: dW[K, N] += A^T[K, M] * dY[M, N].  Both operands arrive pixel-major ([m][channels],
+//   the natural NHWC order), are staged as such, and are transposed for free by ds_read_b64_tr_b16
+//   (bf16) when the fragments are read.  The reduction over M is split across blockIdx.y and
+//   combined with f32 atomics into the (zeroed) flat gradient buffer.
+#include "conv_common.h"
+
+// Shared epilogue of the forward / data-gradient kernels.  `row_m(r)` maps a tile-local output row to
+// its global pixel index (or -1 if it does not exist); `lds_f` is the (no longer read) staging ring.
+template <typename T, int BM, int BN, int WM, int WN, typename RowMap>
+__device__ __forceinline__ void conv_epilogue(f32x4 (&acc)[BM / WM / 16][BN / WN / 16], float* lds_f,
+                                              const NvaeConvGeom& g, const float* __restrict__ bias,
+                                              const T* residual, void* out, int out_f32, int bm, int bn,
+                                              float* stats, int vec_epi, RowMap row_m) {
+    constexpr int NT = WM * WN * 64;
+    constexpr int MI = BM / WM / 16, NI = BN / WN / 16;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave - wm * WN;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int N = g.Cout;
+    // ---- epilogue -------------------------------------------------------------------------
+    // (a) optional BatchNorm statistics of the output tile, straight from the accumulators:
+    //     per column sum and sum of squares over the tile's valid rows -> stats[bm][2][N]
+    if (stats) {
+        __syncthreads();                                  // ring no longer read
+        float* red = lds_f;                         // [WM][BN][2]
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const int nl = wn * (BN / WN) + j * 16 + fr;
+            const int n = bn * BN + nl;
+            const float bv = (bias && n < N) ? bias[n] : 0.f;
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const long m = row_m(wm * (BM / WM) + i * 16 + fq * 4 + r);
+                    const float v = m >= 0 ? acc[i][j][r] + bv : 0.f;
+                    s1 += v; s2 += v * v;
+                }
+            s1 += __shfl_xor(s1, 16, 64); s1 += __shfl_xor(s1, 32, 64);
+            s2 += __shfl_xor(s2, 16, 64); s2 += __shfl_xor(s2, 32, 64);
+            if (fq == 0) { red[(wm * BN + nl) * 2] = s1; red[(wm * BN + nl) * 2 + 1] = s2; }
+        }
+        __syncthreads();
+        for (int nl = tid; nl < BN; nl += NT) {
+            const int n = bn * BN + nl;
+            if (n >= N) continue;
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int w = 0; w < WM; ++w) { s1 += red[(w * BN + nl) * 2]; s2 += red[(w * BN + nl) * 2 + 1]; }
+            stats[((long)bm * 2) * N + n] = s1;
+            stats[((long)bm * 2 + 1) * N + n] = s2;
+        }
+    }
+    // (b) output.  Vector path: each wave stages one 16-row slab of its tile in LDS (f32), then every
+    //     lane stores 8 consecutive columns of one row (16 B bf16 / 32 B f32) - whole-line writes
+    //     instead of the 2-byte column-strided stores the MFMA C layout gives directly.
+    constexpr int WCOLS = BN / WN;
+    constexpr int SROW = WCOLS + 4;                        // padded f32 row
+    constexpr int VPR = WCOLS / 8;                         // 8-column vectors per row
+    if (vec_epi) {
+        __syncthreads();
+        float* st = lds_f + wave * (16 * SROW);
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) st[(fq * 4 + r) * SROW + j * 16 + fr] = acc[i][j][r];
+            __syncthreads();
+            for (int v = lane; v < 16 * VPR; v += 64) {
+                const int row = v / VPR, c8 = v - row * VPR;
+                const long m = row_m(wm * (BM / WM) + i * 16 + row);
+                const int n0 = bn * BN + wn * WCOLS + c8 * 8;
+                if (m < 0 || n0 >= N) continue;
+                float o[8];
+                const float4 lo = *(const float4*)(st + row * SROW + c8 * 8), hi = *(const float4*)(st + row * SROW + c8 * 8 + 4);
+                o[0] = lo.x; o[1] = lo.y; o[2] = lo.z; o[3] = lo.w; o[4] = hi.x; o[5] = hi.y; o[6] = hi.z; o[7] = hi.w;
+                if (n0 + 8 <= N) {
+                    if (bias) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) o[e] += bias[n0 + e];
+                    }
+                    if (residual) {
+                        float rr[8];
+                        V8<T>::ld(residual + m * g.res_ld + n0, rr);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) o[e] += rr[e];
+                    }
+                    if (out_f32) V8<float>::st((float*)out + m * g.out_ld + n0, o);
+                    else V8<T>::st((T*)out + m * g.out_ld + n0, o);
+                } else {
+                    for (int e = 0; e < 8 && n0 + e < N; ++e) {
+                        float vv = o[e] + (bias ? bias[n0 + e] : 0.f);
+                        if (residual) vv += ldf<T>(residual + m * g.res_ld + n0 + e);
+                        if (out_f32) ((float*)out)[m * g.out_ld + n0 + e] = vv;
+                        else stf<T>((T*)out + m * g.out_ld + n0 + e, vv);
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        return;
+    }
+    // scalar path (unaligned channel slices, e.g. SkipScaler's 10-channel outputs)
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+        const int n = bn * BN + wn * (BN / WN) + j * 16 + fr;
+        if (n >= N) continue;
+        const float bv = bias ? bias[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const long m = row_m(wm * (BM / WM) + i * 16 + fq * 4 + r);
+                if (m < 0) continue;
+                float v = acc[i][j][r] + bv;
+                if (residual) v += ldf<T>(residual + m * g.res_ld + n);
+                if (out_f32) ((float*)out)[m * g.out_ld + n] = v;
+                else stf<T>((T*)out + m * g.out_ld + n, v);
+            }
+        }
+    }
+}
+
+// =========================================================================================
+// k_conv_gemm2: the same implicit GEMM with the staging done by LDS-DMA (global_load_lds_dwordx4,
+// no staging registers, no ds_write) into a 3-deep LDS ring, BK = 8 chunks (64 bf16 / 32 f32) per
+// barrier.  The DMA is issued through inline asm so that hipcc does not know about the pending LDS
+// writes (it would otherwise put s_waitcnt vmcnt(0) in front of every ds_read); completion is
+// tracked by hand: one counted s_waitcnt vmcnt(NLOAD) + one raw s_barrier per K-step, with the loads
+// of step t+2 issued right after the barrier of step t (ring slot (t+2)%3 was last read in step t-1,
+// which every wave has finished once it passed that barrier).
+//   LDS image per stage: [BM + BN rows][8 slots of 16 B]; slot = chunk ^ ((row >> 1) & 7): lane-linear
+//   for the DMA (the swizzle is applied to the per-lane SOURCE address) and conflict-free for the
+//   16x16x32 operand reads (checked against the ds_read_b128 16-lane groups).
+//   Out-of-image (padding) and out-of-range lanes read a 16-B zero buffer instead of being masked:
+//   LDS-DMA needs every lane to write its slot.
+// =========================================================================================
+template <typename T, int BM, int BN, int WM, int WN, int STAGES, int BKC>
+__global__ __launch_bounds__(WM* WN * 64) void k_conv_gemm2(
+    NvaeConvGeom g, const T* __restrict__ src, const T* __restrict__ wT, int w_ld,
+    const float* __restrict__ bias, const T* residual, void* out, int out_f32, int M, int K, int n_tiles,
+    int total_tiles, FastDiv fd_hw, FastDiv fd_w, const uint4* __restrict__ zeros, float* stats,
+    int vec_epi) {
+    constexpr int NT = WM * WN * 64;
+    constexpr int VE = Tr<T>::VE;
+    constexpr int BKE = BKC * VE;                  // K elements per ring step (BKC 16-B chunks per row)
+    constexpr int ACH = BM * BKC / NT, BCH = BN * BKC / NT;
+    constexpr int MI = BM / WM / 16, NI = BN / WN / 16;
+    constexpr int STAGE = (BM + BN) * BKC;         // uint4 per ring slot
+    constexpr int NLOAD = ACH + BCH;
+    static_assert(ACH >= 1 && BCH >= 1 && (NT / BKC) % 16 == 0, "tile/thread mismatch");
+    static_assert(BKC == 8 || BKC == 16, "row width");
+    static_assert(STAGES * STAGE * 16 >= WM * WN * 16 * (BN / WN + 4) * 4, "epilogue staging must fit in the ring");
+    static_assert(STAGES * STAGE * 16 >= WM * BN * 2 * 4, "stats scratch must fit in the ring");
+    static_assert(STAGES == 2 || STAGES == 3, "ring depth");
+    __shared__ uint4 lds[STAGES * STAGE];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave - wm * WN;
+    const int tile = xcd_remap(blockIdx.x, total_tiles);
+    const int bm = tile / n_tiles, bn = tile - bm * n_tiles;
+    const int N = g.Cout;
+    const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)lds;
+
+    // ---- per-thread gather state: chunk q = tid + NT*i  ->  row q / BKC, physical slot q % BKC
+    const int row0 = tid / BKC;
+    const int kc = ((tid % BKC) ^ swz_row<BKC>(row0)) * VE;
+    int tap = kc / g.Cin;
+    int ci = kc - tap * g.Cin;
+    int kh = tap / g.KW, kw = tap - kh * g.KW;
+    int kabs = kc;
+    const int hlim = g.Hin * g.div, wlim = g.Win * g.div;
+
+    int hb[ACH], wb[ACH];
+    long pb[ACH];
+    bool mv[ACH];
+#pragma unroll
+    for (int i = 0; i < ACH; ++i) {
+        int m = bm * BM + row0 + (NT / BKC) * i;
+        mv[i] = m < M;
+        unsigned mm = mv[i] ? (unsigned)m : 0u;
+        unsigned b = fdiv(mm, fd_hw);
+        unsigned rem = mm - b * fd_hw.d;
+        unsigned ho = fdiv(rem, fd_w);
+        unsigned wo = rem - ho * fd_w.d;
+        hb[i] = (int)ho * g.stride - g.pad_t;
+        wb[i] = (int)wo * g.stride - g.pad_l;
+        pb[i] = (long)b * g.Hin * g.Win;
+    }
+    const T* bp[BCH];
+    bool nv[BCH];
+#pragma unroll
+    for (int j = 0; j < BCH; ++j) {
+        int n = bn * BN + row0 + (NT / BKC) * j;
+        nv[j] = n < N;
+        bp[j] = wT + (long)(nv[j] ? n : 0) * w_ld;
+    }
+
+    auto issue = [&](int slot) {
+        const bool kval = kabs < K;
+        const unsigned dst = lds_base + (unsigned)(slot * STAGE + wave * 64) * 16u;
+#pragma unroll
+        for (int i = 0; i < ACH; ++i) {
+            int hc = hb[i] + kh, wc = wb[i] + kw;
+            bool ok = mv[i] && kval && hc >= 0 && hc < hlim && wc >= 0 && wc < wlim;
+            int hs = hc, ws = wc;
+            if (g.div != 1) {
+                hs = hc / g.div; ws = wc / g.div;
+                if (g.exact) ok = ok && (hs * g.div == hc) && (ws * g.div == wc);
+            }
+            const void* p = ok ? (const void*)(src + (pb[i] + (long)hs * g.Win + ws) * g.in_ld + ci) : (const void*)zeros;
+            glds16(p, dst + (unsigned)(NT * i) * 16u);
+        }
+#pragma unroll
+        for (int j = 0; j < BCH; ++j) {
+            const void* p = (nv[j] && kval) ? (const void*)(bp[j] + kabs) : (const void*)zeros;
+            glds16(p, dst + (unsigned)(BM * BKC + NT * j) * 16u);
+        }
+        kabs += BKE;
+        ci += BKE;
+        while (ci >= g.Cin) {
+            ci -= g.Cin;
+            if (++kw == g.KW) { kw = 0; ++kh; }
+        }
+    };
+
+    f32x4 acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int nk = (K + BKE - 1) / BKE;
+    const int fr = lane & 15, fq = lane >> 4;
+    issue(0);
+    if (STAGES == 3 && nk > 1) issue(1);
+    int cur = 0;
+    for (int t = 0; t < nk; ++t) {
+        if (STAGES == 3 && t + 1 < nk) wait_vmcnt<NLOAD>();
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        // refill the slot that was read in step t-1 with the tile of step t + STAGES - 1
+        if (t + STAGES - 1 < nk) issue(cur >= 1 ? cur - 1 : STAGES - 1);
+        const uint4* buf = lds + cur * STAGE;
+#pragma unroll
+        for (int h = 0; h < BKC / 4; ++h) {
+            uint4 af[MI], bf[NI];
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                int r = wm * (BM / WM) + i * 16 + fr;
+                af[i] = buf[r * BKC + ((h * 4 + fq) ^ swz_row<BKC>(r))];
+            }
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+                int r = wn * (BN / WN) + j * 16 + fr;
+                bf[j] = buf[BM * BKC + r * BKC + ((h * 4 + fq) ^ swz_row<BKC>(r))];
+            }
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j) mfma_step<T>(af[i], bf[j], acc[i][j]);
+        }
+        cur = cur == STAGES - 1 ? 0 : cur + 1;
+    }
+
+    conv_epilogue<T, BM, BN, WM, WN>(acc, (float*)lds, g, bias, residual, out, out_f32, bm, bn, stats, vec_epi,
+                                     [&](int r) -> long { int m = bm * BM + r; return m < M ? (long)m : -1L; });
+}
+
+// =========================================================================================
+// k_conv_halo: K x K (3 or 5), stride 1, 'same' convolutions on images whose sides are multiples of
+// 16 -- the FLOP-dominant dense 5x5 layers of Postprocess and their data gradients.
+//   k_conv_gemm2 is bound by the bytes it stages: per 64-deep K-step a 256 x 192 tile DMAs 32 KB of
+//   gathered activations + 24 KB of weights, and every activation is fetched again for each of the 25
+//   taps.  Here the M-tile is one 16 x 16 pixel patch: its (16+K-1)^2 halo x 64 channels (51 KB for
+//   K = 5) is DMA'd into LDS ONCE per channel chunk and all K*K taps read their shifted 16 x 16 window
+//   out of it; only the weight tile streams per step (24 KB): 2.1x fewer staged bytes per FLOP and no
+//   per-step gather addressing.  The next chunk's halo is prefetched one DMA pass per step during the
+//   first 7 taps.  LDS: 2 halo buffers + 2 weight slots = 148 KB.
+//   Halo rows are [pixel][8 chunks], slot = chunk ^ (row & 7): conflict-free for the 16x16x32 operand
+//   read at ANY row offset (the tap shift moves the 16-row window by kh*20 + kw rows).
+// =========================================================================================
+template <typename T, int BN, int KS>
+__global__ __launch_bounds__(512) void k_conv_halo(
+    NvaeConvGeom g, const T* __restrict__ src, const T* __restrict__ wT, int w_ld,
+    const float* __restrict__ bias, const T* residual, void* out, int out_f32, int n_tiles, int total_tiles,
+    int patches_w, int patches_per_img, const uint4* __restrict__ zeros, float* stats, int vec_epi) {
+    constexpr int BM = 256, WM = 4, WN = 2, NT = 512;
+    constexpr int VE = Tr<T>::VE;
+    constexpr int CCH = 8 * VE;                       // channels per halo chunk (64 bf16 / 32 f32)
+    constexpr int HP = 16 + KS - 1, HROWS = HP * HP;
+    constexpr int A_CHUNKS = (HROWS * 8 + 63) / 64 * 64;   // whole wave-instructions; the tail DMAs zeros
+    constexpr int A_PASSES = (A_CHUNKS + NT - 1) / NT;
+    constexpr int B_CHUNKS = BN * 8, BCH = B_CHUNKS / NT;
+    constexpr int MI = 4, NI = BN / WN / 16;
+    constexpr int PAD = (KS - 1) / 2, TAPS = KS * KS;
+    static_assert(B_CHUNKS % NT == 0 && A_PASSES <= TAPS, "tile/thread mismatch");
+    __shared__ uint4 lds[2 * A_CHUNKS + 2 * B_CHUNKS];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave - wm * WN;
+    const int tile = xcd_remap(blockIdx.x, total_tiles);
+    const int bp = tile / n_tiles, bn = tile - bp * n_tiles;
+    const int b = bp / patches_per_img, pidx = bp - b * patches_per_img;
+    const int py0 = (pidx / patches_w) * 16, px0 = (pidx % patches_w) * 16;
+    const int N = g.Cout, H = g.Hin, W = g.Win;
+    const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)lds;
+
+    const int row0 = tid >> 3, phys = tid & 7;
+    const int sc = (phys ^ (row0 & 7)) * VE;          // this thread's element offset inside a chunk row
+    // weight rows of this thread
+    const T* bp_[BCH];
+    bool nv[BCH];
+#pragma unroll
+    for (int j = 0; j < BCH; ++j) {
+        int n = bn * BN + row0 + (NT / 8) * j;
+        nv[j] = n < N;
+        bp_[j] = wT + (long)(nv[j] ? n : 0) * w_ld + sc;
+    }
+    // halo pixels of this thread (one per DMA pass)
+    long apix[A_PASSES];                               // pixel offset (elements) or -1
+#pragma unroll
+    for (int i = 0; i < A_PASSES; ++i) {
+        const int hrow = row0 + (NT / 8) * i;
+        apix[i] = -1;
+        if (hrow < HROWS) {
+            const int hy = hrow / HP, hx = hrow - hy * HP;
+            const int iy = py0 - PAD + hy, ix = px0 - PAD + hx;
+            if (iy >= 0 && iy < H && ix >= 0 && ix < W) apix[i] = (((long)b * H + iy) * W + ix) * g.in_ld + sc;
+        }
+    }
+    auto issue_a = [&](int buf, int cc, int i) {
+        // pass i covers chunks [NT*i, NT*i + NT): wave-uniform validity (A_CHUNKS is a multiple of 64)
+        if (NT * i + wave * 64 >= A_CHUNKS) return;
+        const void* p = apix[i] >= 0 ? (const void*)(src + apix[i] + (long)cc * CCH) : (const void*)zeros;
+        glds16(p, lds_base + (unsigned)(buf * A_CHUNKS + NT * i + wave * 64) * 16u);
+    };
+    auto issue_b = [&](int slot, int cc, int tap) {
+        const long k = (long)tap * g.Cin + (long)cc * CCH;
+#pragma unroll
+        for (int j = 0; j < BCH; ++j) {
+            const void* p = nv[j] ? (const void*)(bp_[j] + k) : (const void*)zeros;
+            glds16(p, lds_base + (unsigned)(2 * A_CHUNKS + slot * B_CHUNKS + NT * j + wave * 64) * 16u);
+        }
+    };
+
+    f32x4 acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int ncc = g.Cin / CCH;
+    const int S = ncc * TAPS;
+    const int fr = lane & 15, fq = lane >> 4;
+#pragma unroll
+    for (int i = 0; i < A_PASSES; ++i) issue_a(0, 0, i);
+    issue_b(0, 0, 0);
+    int cc = 0, tap = 0;
+    for (int s = 0; s < S; ++s) {
+        wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        {   // prefetch: next weight tile, and one pass of the next chunk's halo
+            int ntap = tap + 1, ncc_ = cc;
+            if (ntap == TAPS) { ntap = 0; ++ncc_; }
+            if (s + 1 < S) issue_b((s + 1) & 1, ncc_, ntap);
+            if (tap < A_PASSES && cc + 1 < ncc) {
+#pragma unroll
+                for (int i = 0; i < A_PASSES; ++i)
+                    if (i == tap) issue_a((cc + 1) & 1, cc + 1, i);
+            }
+        }
+        const uint4* abuf = lds + (cc & 1) * A_CHUNKS;
+        const uint4* bbuf = lds + 2 * A_CHUNKS + (s & 1) * B_CHUNKS;
+        const int kh = tap / KS, kw = tap - kh * KS;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            uint4 af[MI], bf[NI];
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                const int hrow = (wm * 4 + i + kh) * HP + kw + fr;
+                af[i] = abuf[hrow * 8 + ((h * 4 + fq) ^ (hrow & 7))];
+            }
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+                const int r = wn * (BN / WN) + j * 16 + fr;
+                bf[j] = bbuf[r * 8 + ((h * 4 + fq) ^ (r & 7))];
+            }
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j) mfma_step<T>(af[i], bf[j], acc[i][j]);
+        }
+        if (++tap == TAPS) { tap = 0; ++cc; }
+    }
+    conv_epilogue<T, BM, BN, WM, WN>(acc, (float*)lds, g, bias, residual, out, out_f32, bp, bn, stats, vec_epi,
+                                     [&](int r) -> long { return ((long)b * H + py0 + (r >> 4)) * W + px0 + (r & 15); });
+}
+
+// halo kernel eligibility (must agree between the launcher and nvae_conv_gemm_mtiles)
+static bool conv_halo_ok(int dtype, const NvaeConvGeom* g) {
+    const int cch = dtype == NVAE_BF16 ? 64 : 32;
+    const int N = g->Cout;
+    const long w192 = (long)cdiv(N, 192) * 192, w128 = (long)cdiv(N, 128) * 128;
+    return g->KH == g->KW && (g->KH == 5 || g->KH == 3) && g->stride == 1 && g->div == 1 &&
+           g->pad_t == (g->KH - 1) / 2 && g->pad_l == (g->KW - 1) / 2 && g->Hin == g->Hout && g->Win == g->Wout &&
+           g->Hin % 16 == 0 && g->Win % 16 == 0 && g->Cin % cch == 0 && g->Cin >= 2 * cch && w192 <= w128 &&
+           (long)g->B * (g->Hin / 16) * (g->Win / 16) * cdiv(N, 192) >= 64;
+}
+
+static int conv_gemm_bm(int dtype, const NvaeConvGeom* g) {
+    // M-tile height the launcher will pick (must match launch_conv_gemm)
+    if (conv_halo_ok(dtype, g)) return 256;
+    const int M = g->B * g->Hout * g->Wout, K = g->KH * g->KW * g->Cin, N = g->Cout;
+    const long big_tiles = (long)cdiv(M, 128) * cdiv(N, 128);
+    const long w192 = (long)cdiv(N, 192) * 192, w128 = (long)cdiv(N, 128) * 128, w64 = (long)cdiv(N, 64) * 64;
+    if ((long)cdiv(M, 256) * cdiv(N, 192) >= 224 && w192 <= w128 && w192 <= w64 && K >= 1024) return 256;
+    if (big_tiles >= 192) return 128;
+    return 64;
+}
+
+template <typename T>
+static int launch_conv_gemm(const NvaeConvGeom* g, const void* src, const void* wT, int w_ld,
+                            const float* bias, const void* residual, void* out, int out_f32,
+                            float* stats, hipStream_t s) {
+    const int M = g->B * g->Hout * g->Wout, K = g->KH * g->KW * g->Cin, N = g->Cout;
+    FastDiv fd_hw = make_fastdiv((unsigned)(g->Hout * g->Wout)), fd_w = make_fastdiv((unsigned)g->Wout);
+    const uint4* zeros = zero_page();
+    // 16-B row-contiguous stores need aligned rows; otherwise the scalar epilogue
+    const int vo = out_f32 ? 4 : (int)(16 / sizeof(T));
+    const int vec_epi = (g->out_ld % vo == 0) && aligned16(out) &&
+                        (!residual || (g->res_ld % (int)(16 / sizeof(T)) == 0 && aligned16(residual)));
+    if (conv_halo_ok(sizeof(T) == 2 ? NVAE_BF16 : NVAE_F32, g)) {
+        const int pw = g->Win / 16, ppi = (g->Hin / 16) * pw;
+        const int mt = g->B * ppi, nt = cdiv(N, 192);
+        if (g->KH == 5)
+            hipLaunchKernelGGL((k_conv_halo<T, 192, 5>), mt * nt, 512, 0, s, *g, (const T*)src, (const T*)wT, w_ld, bias,
+                               (const T*)residual, out, out_f32, nt, mt * nt, pw, ppi, zeros, stats, vec_epi);
+        else
+            hipLaunchKernelGGL((k_conv_halo<T, 192, 3>), mt * nt, 512, 0, s, *g, (const T*)src, (const T*)wT, w_ld, bias,
+                               (const T*)residual, out, out_f32, nt, mt * nt, pw, ppi, zeros, stats, vec_epi);
+        return 0;
+    }
+#define LAUNCH2(BM_, BN_, WM_, WN_, ST_, BKC_)                                                          \
+    {                                                                                                   \
+        int mt = cdiv(M, BM_), nt = cdiv(N, BN_);                                                       \
+        hipLaunchKernelGGL((k_conv_gemm2<T, BM_, BN_, WM_, WN_, ST_, BKC_>), mt * nt, WM_ * WN_ * 64, 0, s, *g, \
+                           (const T*)src, (const T*)wT, w_ld, bias, (const T*)residual, out, out_f32, M, \
+                           K, nt, mt * nt, fd_hw, fd_w, zeros, stats, vec_epi);                         \
+    }
+    // Large problems: 128-row tiles, 8 waves; N tile with the least padding (ties -> larger).
+    // Small problems (few tiles): 64 x 64 tiles, 4 waves, so that the grid covers the chip.
+    const long big_tiles = (long)cdiv(M, 128) * cdiv(N, 128);
+    const long w192 = (long)cdiv(N, 192) * 192, w128 = (long)cdiv(N, 128) * 128, w64 = (long)cdiv(N, 64) * 64;
+    if ((long)cdiv(M, 256) * cdiv(N, 192) >= 224 && w192 <= w128 && w192 <= w64 && K >= 1024) {
+        // the FLOP-dominant layers: 256 x 192 tile (112 FLOP per staged byte), 2-deep ring (112 KB)
+        LAUNCH2(256, 192, 4, 2, 2, 8)
+    } else if (big_tiles >= 192) {
+        if (w192 <= w128 && w192 <= w64) LAUNCH2(128, 192, 2, 4, 3, 8)
+        else if (w128 <= w64) LAUNCH2(128, 128, 2, 4, 3, 8)
+        else LAUNCH2(128, 64, 4, 2, 3, 8)
+    } else if (K >= 512) {
+        // small M: latency-bound K loop -> 8 waves, 128-deep ring steps (half the barriers)
+        LAUNCH2(64, 64, 2, 4, 3, 16)
+    } else {
+        LAUNCH2(64, 64, 2, 2, 3, 8)
+    }
+#undef LAUNCH2
+    return 0;
+}
+
+extern "C" int nvae_conv_gemm_mtiles(int dtype, const NvaeConvGeom* g) {
+    if (!g) return 0;
+    return cdiv((long)g->B * g->Hout * g->Wout, conv_gemm_bm(dtype, g));
+}
+
+extern "C" int nvae_conv_gemm(int dtype, const NvaeConvGeom* g, const void* src, const void* wT, int w_ld,
+                              const float* bias, const void* residual, void* out, int out_f32,
+                              float* stats, void* stream) {
+    if (int e = check_geom_mfma("conv_gemm", g)) return e;
+    NVAE_REQUIRE(src && wT && out, "conv_gemm: NULL pointer");
+    const int ve = (dtype == NVAE_BF16) ? 8 : 4;
+    NVAE_REQUIRE(g->Cin % ve == 0 && g->in_ld % ve == 0 && w_ld % ve == 0,
+                 "conv_gemm: Cin=%d in_ld=%d w_ld=%d must be multiples of %d (use nvae_conv_direct)", g->Cin, g->in_ld, w_ld, ve);
+    NVAE_REQUIRE(w_ld >= g->KH * g->KW * g->Cin, "conv_gemm: w_ld too small");
+    NVAE_REQUIRE(aligned16(src) && aligned16(wT), "conv_gemm: src/wT must be 16-B aligned");
+    NVAE_REQUIRE(!residual || g->res_ld >= g->Cout, "conv_gemm: res_ld too small");
+    DISPATCH_T(dtype, launch_conv_gemm<T>(g, src, wT, w_ld, bias, residual, out, out_f32, stats, (hipStream_t)stream);)
+    NVAE_LAUNCH_CHECK("conv_gemm");
+    return NVAE_OK;
+}
+

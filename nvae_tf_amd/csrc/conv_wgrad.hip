@@ -1,0 +1,334 @@
+// Weight-gradient implicit GEMM (see conv_gemm.hip for the forward / data-gradient kernels).
+#include "conv_common.h"
+
+// =========================================================================================
+// k_conv_wgrad2: weight gradient with the LDS-DMA ring.  Per ring step RS = 8 chunks-worth of pixels
+// (64 bf16 / 32 f32) of the pixel-major x-gather [RS][KT] and dy [RS][NTL] images are DMA'd into LDS;
+// the images keep the XOR-swizzled 32-B segment layout of k_conv_wgrad (transposing ds_read_b64_tr_b16
+// fragment reads), with the swizzle moved to the DMA's per-lane source address.
+// =========================================================================================
+template <typename T, int COLS>
+__device__ __forceinline__ int img_src_chunk(int m, int pc) {
+    // inverse of img_off: which logical 16-B chunk lands at physical chunk `pc` of pixel row `m`
+    if constexpr (sizeof(T) == 2) {
+        int s = (COLS >= 128) ? ((m & 3) | (((m >> 3) & 1) << 2)) : (((m >> 1) & 1) | (((m >> 3) & 1) << 1));
+        return (((pc >> 1) ^ s) << 1) | (pc & 1);
+    } else {
+        return (((pc >> 2) ^ (m & 1)) << 2) | (pc & 3);
+    }
+}
+
+template <typename T, int KT, int NTL, int WK, int WN, int STAGES>
+__global__ __launch_bounds__(WK* WN * 64) void k_conv_wgrad2(
+    NvaeConvGeom g, const T* __restrict__ x, const T* __restrict__ dy, float* dw, int dw_ld, float* db,
+    int M, int K, int n_tiles, int m_per_split, FastDiv fd_hw, FastDiv fd_w,
+    const uint4* __restrict__ zeros, float* slab) {
+    constexpr int NT = WK * WN * 64;
+    constexpr int VE = Tr<T>::VE;
+    constexpr int RS = 8 * VE;                      // pixels per ring step
+    constexpr int CPR_A = KT / VE, CPR_B = NTL / VE;
+    constexpr int ACH = RS * CPR_A / NT, BCH = RS * CPR_B / NT;
+    constexpr int MI = KT / WK / 16, NI = NTL / WN / 16;
+    constexpr int A_BYTES = RS * KT * (int)sizeof(T), B_BYTES = RS * NTL * (int)sizeof(T);
+    constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
+    constexpr int NLOAD = ACH + BCH;
+    static_assert(ACH >= 1 && BCH >= 1, "tile/thread mismatch");
+    static_assert((NT / CPR_A) % 16 == 0 || sizeof(T) == 4, "A rows per pass must keep the swizzle invariant");
+    static_assert((NT / CPR_B) % 16 == 0 || sizeof(T) == 4, "B rows per pass must keep the swizzle invariant");
+    static_assert((NT / CPR_A) % 2 == 0 && (NT / CPR_B) % 2 == 0, "row step parity");
+    __shared__ __attribute__((aligned(16))) unsigned char lds[STAGES * STAGE_BYTES];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wk = wave / WN, wn = wave - wk * WN;
+    // consecutive tiles (the n-tiles of one k-tile, then the next k-tile) share an XCD's L2
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int kt = tile / n_tiles, nt = tile - kt * n_tiles;
+    const int k0 = kt * KT, n0 = nt * NTL;
+    const int N = g.Cout;
+    const int m_begin = blockIdx.y * m_per_split;
+    int m_end = m_begin + m_per_split;
+    if (m_end > M) m_end = M;
+    const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)lds;
+
+    // A side: physical chunk (a_row0 + pass*rows, a_pc); logical k column fixed per thread
+    const int a_pc = tid % CPR_A, a_row0 = tid / CPR_A;
+    const int kcol = k0 + img_src_chunk<T, KT>(a_row0, a_pc) * VE;
+    const bool kval = kcol < K;
+    const int tap = kval ? kcol / g.Cin : 0;
+    const int ci = kval ? kcol - tap * g.Cin : 0;
+    const int kh = tap / g.KW, kw = tap - kh * g.KW;
+    const int hlim = g.Hin * g.div, wlim = g.Win * g.div;
+    const int b_pc = tid % CPR_B, b_row0 = tid / CPR_B;
+    const int ncol = n0 + img_src_chunk<T, NTL>(b_row0, b_pc) * VE;
+    const bool nval = ncol < N;
+
+    auto issue = [&](int slot, int mbase) {
+        const unsigned dst = lds_base + (unsigned)(slot * STAGE_BYTES) + (unsigned)(wave * 64) * 16u;
+#pragma unroll
+        for (int i = 0; i < ACH; ++i) {
+            const int m = mbase + a_row0 + i * (NT / CPR_A);
+            const void* p = zeros;
+            if (kval && m < m_end) {
+                unsigned b = fdiv((unsigned)m, fd_hw);
+                unsigned rem = (unsigned)m - b * fd_hw.d;
+                unsigned ho = fdiv(rem, fd_w);
+                unsigned wo = rem - ho * fd_w.d;
+                int hc = (int)ho * g.stride - g.pad_t + kh, wc = (int)wo * g.stride - g.pad_l + kw;
+                bool ok = hc >= 0 && hc < hlim && wc >= 0 && wc < wlim;
+                int hs = hc, ws = wc;
+                if (g.div != 1) {
+                    hs = hc / g.div; ws = wc / g.div;
+                    if (g.exact) ok = ok && (hs * g.div == hc) && (ws * g.div == wc);
+                }
+                if (ok) p = x + ((long)b * g.Hin * g.Win + (long)hs * g.Win + ws) * g.in_ld + ci;
+            }
+            glds16(p, dst + (unsigned)(NT * i) * 16u);
+        }
+#pragma unroll
+        for (int j = 0; j < BCH; ++j) {
+            const int m = mbase + b_row0 + j * (NT / CPR_B);
+            const void* p = (nval && m < m_end) ? (const void*)(dy + (long)m * g.out_ld + ncol) : (const void*)zeros;
+            glds16(p, dst + (unsigned)A_BYTES + (unsigned)(NT * j) * 16u);
+        }
+    };
+
+    f32x4 acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const bool do_bias = (db != nullptr) && (kt == 0);
+    float bsum[VE];
+#pragma unroll
+    for (int j = 0; j < VE; ++j) bsum[j] = 0.f;
+
+    const int fr = lane & 15, fq = lane >> 4;
+    const int nsteps = (m_end - m_begin + RS - 1) / RS;
+    if (nsteps > 0) issue(0, m_begin);
+    if (STAGES == 3 && nsteps > 1) issue(1, m_begin + RS);
+    int cur = 0;
+    for (int t = 0; t < nsteps; ++t) {
+        if (STAGES == 3 && t + 1 < nsteps) wait_vmcnt<NLOAD>();
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (t + STAGES - 1 < nsteps) issue(cur >= 1 ? cur - 1 : STAGES - 1, m_begin + (t + STAGES - 1) * RS);
+        const unsigned char* bufA = lds + cur * STAGE_BYTES;
+        const unsigned char* bufB = bufA + A_BYTES;
+        if (do_bias) {
+            // re-read this thread's own DMA'd dy chunks (fixed column, RS/(NT/CPR_B) rows)
+#pragma unroll
+            for (int j = 0; j < BCH; ++j) {
+                uint4 v = *(const uint4*)(bufB + (tid + NT * j) * 16);
+                if constexpr (sizeof(T) == 2) {
+                    bsum[0] += __uint_as_float(v.x << 16); bsum[1] += __uint_as_float(v.x & 0xffff0000u);
+                    bsum[2] += __uint_as_float(v.y << 16); bsum[3] += __uint_as_float(v.y & 0xffff0000u);
+                    bsum[4] += __uint_as_float(v.z << 16); bsum[5] += __uint_as_float(v.z & 0xffff0000u);
+                    bsum[6] += __uint_as_float(v.w << 16); bsum[7] += __uint_as_float(v.w & 0xffff0000u);
+                } else {
+                    bsum[0] += __uint_as_float(v.x); bsum[1] += __uint_as_float(v.y);
+                    bsum[2] += __uint_as_float(v.z); bsum[3] += __uint_as_float(v.w);
+                }
+            }
+        }
+        if constexpr (sizeof(T) == 2) {
+            const int q = fr >> 2, p = fr & 3;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const int mr = ks * 32 + 8 * fq + q, mr1 = mr + 4;
+                const int s8_0 = (mr & 3) | (((mr >> 3) & 1) << 2), s8_1 = (mr1 & 3) | (((mr1 >> 3) & 1) << 2);
+                const int s4_0 = ((mr >> 1) & 1) | (((mr >> 3) & 1) << 1), s4_1 = ((mr1 >> 1) & 1) | (((mr1 >> 3) & 1) << 1);
+                const int sa0 = KT >= 128 ? s8_0 : s4_0, sa1 = KT >= 128 ? s8_1 : s4_1;
+                const int sb0 = NTL >= 128 ? s8_0 : s4_0, sb1 = NTL >= 128 ? s8_1 : s4_1;
+                bf16x8 af[MI], bfr[NI];
+#pragma unroll
+                for (int i = 0; i < MI; ++i) {
+                    const int seg = wk * (KT / WK / 16) + i;
+                    auto lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                        (__attribute__((address_space(3))) bf16x4*)(bufA + mr * (KT * 2) + ((seg ^ sa0) << 5) + p * 8));
+                    auto hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                        (__attribute__((address_space(3))) bf16x4*)(bufA + mr1 * (KT * 2) + ((seg ^ sa1) << 5) + p * 8));
+                    af[i] = (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                }
+#pragma unroll
+                for (int j = 0; j < NI; ++j) {
+                    const int seg = wn * (NTL / WN / 16) + j;
+                    auto lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                        (__attribute__((address_space(3))) bf16x4*)(bufB + mr * (NTL * 2) + ((seg ^ sb0) << 5) + p * 8));
+                    auto hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                        (__attribute__((address_space(3))) bf16x4*)(bufB + mr1 * (NTL * 2) + ((seg ^ sb1) << 5) + p * 8));
+                    bfr[j] = (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                }
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NI; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int sI = 0; sI < RS / 4; ++sI) {
+                const int m = 4 * sI + fq;
+                float af[MI], bfr[NI];
+#pragma unroll
+                for (int i = 0; i < MI; ++i) {
+                    int col = wk * (KT / WK) + i * 16 + fr;
+                    af[i] = *(const float*)(bufA + m * (KT * 4) + (((col >> 4) ^ (m & 1)) << 6) + ((col & 15) << 2));
+                }
+#pragma unroll
+                for (int j = 0; j < NI; ++j) {
+                    int col = wn * (NTL / WN) + j * 16 + fr;
+                    bfr[j] = *(const float*)(bufB + m * (NTL * 4) + (((col >> 4) ^ (m & 1)) << 6) + ((col & 15) << 2));
+                }
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NI; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bfr[j], acc[i][j], 0, 0, 0);
+            }
+        }
+        cur = cur == STAGES - 1 ? 0 : cur + 1;
+    }
+
+    // With a slab, every split writes its partial [K + 1][N] block (row K = bias) with plain stores and
+    // k_slab_reduce sums the splits; without, f32 atomics into the gradient buffer.
+    float* part = slab ? slab + (long)blockIdx.y * (K + 1) * N : nullptr;
+    if (do_bias) {
+        __syncthreads();
+        float* red = (float*)lds;                    // [NT / CPR_B rows][CPR_B][VE]
+#pragma unroll
+        for (int j = 0; j < VE; ++j) red[tid * VE + j] = bsum[j];
+        __syncthreads();
+        if (tid < CPR_B * VE) {
+            // logical column (chunk lc, element j): physical chunk differs per row through the swizzle
+            const int lc = tid / VE, j = tid - lc * VE;
+            float a = 0.f;
+            for (int r = 0; r < NT / CPR_B; ++r) {
+                int pc = img_src_chunk<T, NTL>(r, lc);      // the swizzle is an involution
+                a += red[(r * CPR_B + pc) * VE + j];
+            }
+            const int n = n0 + lc * VE + j;
+            if (n < N) {
+                if (part) part[(long)K * N + n] = a;
+                else atomicAdd(db + n, a);
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+        const int n = n0 + wn * (NTL / WN) + j * 16 + fr;
+        if (n >= N) continue;
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int k = k0 + wk * (KT / WK) + i * 16 + fq * 4 + r;
+                if (k < K) {
+                    if (part) part[(long)k * N + n] = acc[i][j][r];
+                    else atomicAdd(dw + (long)k * dw_ld + n, acc[i][j][r]);
+                }
+            }
+    }
+}
+
+// dw[k*dw_ld + n] += sum_s slab[s][k][n]  (k < K);  db[n] += sum_s slab[s][K][n].  32 outputs per
+// workgroup, 8 lane groups walk the splits in parallel.
+__global__ void k_slab_reduce(const float* __restrict__ slab, int S, int K, int N, float* dw, int dw_ld,
+                              float* db) {
+    __shared__ float sm[8][32];
+    const int ol = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    const long total = (long)(K + 1) * N;
+    const long i = (long)blockIdx.x * 32 + ol;
+    float a = 0.f;
+    if (i < total)
+        for (int s = sl; s < S; s += 8) a += slab[(long)s * total + i];
+    sm[sl][ol] = a;
+    __syncthreads();
+    if (sl != 0 || i >= total) return;
+#pragma unroll
+    for (int k = 1; k < 8; ++k) a += sm[k][ol];
+    const int k = (int)(i / N), n = (int)(i - (long)k * N);
+    if (k < K) dw[(long)k * dw_ld + n] += a;
+    else if (db) db[n] += a;
+}
+
+// Split policy shared by the launcher and the scratch-size query.
+struct WgradPlan { int cfg, tiles, n_tiles, nsplit, mps; bool slab; };
+template <typename T>
+static WgradPlan plan_conv_wgrad(const NvaeConvGeom* g, long scratch_floats) {
+    constexpr int RS = 8 * Tr<T>::VE;
+    const int M = g->B * g->Hout * g->Wout, K = g->KH * g->KW * g->Cin, N = g->Cout;
+    const long flops = 2L * M * K * N;
+    WgradPlan p;
+    int KT, NTL;
+    if (flops >= (1L << 36) && N >= 128 && K >= 256) { p.cfg = 0; KT = 256; NTL = 128; }
+    else if (flops >= (1L << 32) && N >= 128 && K >= 128) { p.cfg = 1; KT = 128; NTL = 128; }
+    else { p.cfg = 2; KT = 64; NTL = 64; }
+    p.n_tiles = cdiv(N, NTL);
+    p.tiles = cdiv(K, KT) * p.n_tiles;
+    // enough workgroups to fill the chip (one wave of 256 for the 8-wave config, ~2 per CU otherwise),
+    // at least 4 ring steps each
+    int nsplit = (p.cfg == 0 ? 256 : 512) / p.tiles;
+    int max_split = M / (RS * 4);
+    if (nsplit > max_split) nsplit = max_split;
+    if (nsplit > 256) nsplit = 256;
+    if (nsplit < 1) nsplit = 1;
+    auto settle = [&](int want) {
+        int mps = cdiv(M, want);
+        mps = ((mps + RS - 1) / RS) * RS;
+        p.mps = mps;
+        p.nsplit = cdiv(M, mps);
+    };
+    settle(nsplit);
+    // > 4 splits are combined through a slab (same-address f32 atomics serialise, ~0.3 us each);
+    // without enough scratch fall back to 4 atomically combined splits
+    p.slab = p.nsplit > 4;
+    if (p.slab && scratch_floats < (long)p.nsplit * (K + 1) * N) {
+        p.slab = false;
+        settle(4);
+    }
+    return p;
+}
+
+template <typename T>
+static int launch_conv_wgrad(const NvaeConvGeom* g, const void* x, const void* dy, float* dw, int dw_ld,
+                             float* db, float* scratch, long scratch_floats, hipStream_t s) {
+    const int M = g->B * g->Hout * g->Wout, K = g->KH * g->KW * g->Cin, N = g->Cout;
+    FastDiv fd_hw = make_fastdiv((unsigned)(g->Hout * g->Wout)), fd_w = make_fastdiv((unsigned)g->Wout);
+    const uint4* zeros = zero_page();
+    const WgradPlan p = plan_conv_wgrad<T>(g, scratch ? scratch_floats : 0);
+    float* slab = p.slab ? scratch : nullptr;
+    dim3 grid(p.tiles, p.nsplit);
+#define LAUNCHW(KT_, NTL_, WK_, WN_, ST_)                                                               \
+    hipLaunchKernelGGL((k_conv_wgrad2<T, KT_, NTL_, WK_, WN_, ST_>), grid, WK_ * WN_ * 64, 0, s, *g,    \
+                       (const T*)x, (const T*)dy, dw, dw_ld, db, M, K, p.n_tiles, p.mps, fd_hw, fd_w,   \
+                       zeros, slab);
+    if (p.cfg == 0) LAUNCHW(256, 128, 4, 2, 3)
+    else if (p.cfg == 1) LAUNCHW(128, 128, 2, 2, 3)
+    else LAUNCHW(64, 64, 2, 2, 3)
+#undef LAUNCHW
+    if (slab)
+        hipLaunchKernelGGL(k_slab_reduce, cdiv((long)(K + 1) * N, 32), 256, 0, s, slab, p.nsplit, K, N, dw, dw_ld, db);
+    return 0;
+}
+
+extern "C" long nvae_conv_wgrad_scratch(int dtype, const NvaeConvGeom* g) {
+    if (!g) return 0;
+    const long K = (long)g->KH * g->KW * g->Cin, N = g->Cout;
+    WgradPlan p = dtype == NVAE_BF16 ? plan_conv_wgrad<bf16>(g, 1L << 60) : plan_conv_wgrad<float>(g, 1L << 60);
+    return p.slab ? (long)p.nsplit * (K + 1) * N : 0;
+}
+
+extern "C" int nvae_conv_wgrad(int dtype, const NvaeConvGeom* g, const void* x, const void* dy, float* dw,
+                               int dw_ld, float* db, float* scratch, long scratch_floats, void* stream) {
+    if (int e = check_geom_mfma("conv_wgrad", g)) return e;
+    NVAE_REQUIRE(x && dy && dw && dw_ld >= g->Cout, "conv_wgrad: bad args");
+    const int ve = (dtype == NVAE_BF16) ? 8 : 4;
+    NVAE_REQUIRE(g->Cin % ve == 0 && g->in_ld % ve == 0 && g->Cout % ve == 0 && g->out_ld % ve == 0,
+                 "conv_wgrad: Cin=%d Cout=%d and their lds must be multiples of %d (use nvae_conv_direct_wgrad)", g->Cin, g->Cout, ve);
+    NVAE_REQUIRE(aligned16(x) && aligned16(dy), "conv_wgrad: x/dy must be 16-B aligned");
+    DISPATCH_T(dtype, launch_conv_wgrad<T>(g, x, dy, dw, dw_ld, db, scratch, scratch_floats, (hipStream_t)stream);)
+    NVAE_LAUNCH_CHECK("conv_wgrad");
+    return NVAE_OK;
+}

@@ -186,7 +186,7 @@ def conv2d(ctx: Ctx, x: Var, conv, *, stride: int = 1, up: int = 1, pad: Optiona
         slab = None
         if want_stats and ctx.training and not accumulate and out_coff == 0 and Cy == cout:
             # the conv's epilogue emits the BatchNorm statistics of its output (consumed by bn_act)
-            S = L.load().nvae_conv_gemm_mtiles(C.byref(g))
+            S = L.load().nvae_conv_gemm_mtiles(ctx.dt, C.byref(g))
             slab = ctx.empty((S, 2, cout), torch.float32)
             out.stats = (slab, S)
         call("nvae_conv_gemm", ctx.dt, C.byref(g), ptr(x.t), wT, conv.wf_ld, bias_ptr, res_ptr, out_ptr,
