@@ -174,7 +174,7 @@ def main():
                        "parallelism": f"dp{world}", "hip_graph": not args.no_graph},
             "loss_nats": loss,
             "e2e_mfma_frac": value / world * TRAIN_FLOP_PER_IMG / 1e12 / PEAK_BF16_TFLOPS,
-            "roofline": {"bound": "mfma", "kernel": "k_conv_gemm2<bf16,256,192,4,2,2,8> (dense 5x5 implicit GEMM of Postprocess, fwd + dgrad)",
+            "roofline": {"bound": "mfma", "kernel": "k_conv_halo<bf16,192,5> (dense 5x5 implicit GEMM of Postprocess, fwd + dgrad)",
                          "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_BF16_TFLOPS, "traffic": traffic,
                          "traffic_unit": "bytes per launch (2*FETCH_SIZE + WRITE_SIZE, rocprofv3 --pmc)",
