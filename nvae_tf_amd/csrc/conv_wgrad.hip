@@ -253,6 +253,195 @@ __global__ void k_slab_reduce(const float* __restrict__ slab, int S, int K, int 
     else if (db) db[n] += a;
 }
 
+// =========================================================================================
+// k_wgrad_halo (bf16): weight gradient of the dense K x K stride-1 'same' layers (the FLOP-dominant 5x5
+// convs).  k_conv_wgrad2 re-streams x and dy once per k-tile, i.e. once per tap: 85 FLOP per staged
+// byte, L2/Infinity-Cache bound at ~450 TFLOP/s.  Here a workgroup owns one kernel row kh, 64 input
+// channels and 192 output channels and keeps the K taps' [64 x 192] accumulators in registers
+// (K * 6 MFMA blocks per wave = 120 VGPRs for K = 5).  Per step it DMAs, for one 8 x 16 pixel
+// half-patch, the x halo rows of its kh ([8][16+K-1] pixels x 64 ch = 20 KB) and the dy tile
+// ([128 px][192] = 48 KB) ONCE and feeds all K taps from them: 231 FLOP per staged byte.
+//   Both images are pixel-major and read with the transposing ds_read_b64_tr_b16.  x rows (128 B) use
+//   the 4-segment swizzle keyed on the HALO row, which is conflict-free at any tap shift; dy rows
+//   (384 B = 12 segments) swizzle segments 0-7 with the 8-segment key and 8-11 with the 4-segment key.
+// =========================================================================================
+__device__ __forceinline__ int seg_s8(int m) { return (m & 3) | (((m >> 3) & 1) << 2); }
+__device__ __forceinline__ int seg_s4(int m) { return ((m >> 1) & 1) | (((m >> 3) & 1) << 1); }
+
+template <int KS>
+__global__ __launch_bounds__(512) void k_wgrad_halo(NvaeConvGeom g, const bf16* __restrict__ x,
+                                                    const bf16* __restrict__ dy, float* dw, int dw_ld,
+                                                    int n_tiles, int cchunks, int hp_per_split,
+                                                    int hp_w /*W/16*/, int hp_per_img /*(H/8)*(W/16)*/,
+                                                    int hp_total, const uint4* __restrict__ zeros) {
+    constexpr int NT = 512, NTL = 192, CCH = 64;
+    constexpr int HW_ = 16 + KS - 1;                     // halo width in pixels
+    constexpr int A_ROWS = 8 * HW_;                      // halo pixels per step (one kernel row)
+    constexpr int A_CHUNKS = (A_ROWS * 8 + 63) / 64 * 64;
+    constexpr int A_PASSES = (A_CHUNKS + NT - 1) / NT;
+    constexpr int B_CHUNKS = 128 * 24, BCH = B_CHUNKS / NT;   // 6
+    constexpr int A_BYTES = A_CHUNKS * 16, B_BYTES = B_CHUNKS * 16;
+    constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
+    constexpr int PAD = (KS - 1) / 2;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * STAGE_BYTES];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wk = wave >> 2, wn = wave & 3;             // 2 (ci halves of 32) x 4 (n quarters of 48)
+    // blockIdx.x = ((cc * n_tiles) + nt) * KS + kh ; blockIdx.y = pixel split
+    const int kh = blockIdx.x % KS;
+    const int t2 = blockIdx.x / KS;
+    const int nt = t2 % n_tiles, cc = t2 / n_tiles;
+    const int n0 = nt * NTL, ci0 = cc * CCH;
+    const int H = g.Hin, W = g.Win;
+    const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)lds;
+
+    // ---- per-thread DMA constants
+    // x halo: chunk q = tid + NT*i -> halo pixel q >> 3, physical chunk q & 7 (16 B = 8 channels)
+    int a_hy[A_PASSES], a_hx[A_PASSES], a_col[A_PASSES];
+#pragma unroll
+    for (int i = 0; i < A_PASSES; ++i) {
+        const int q = tid + NT * i, hrow = q >> 3, pc = q & 7;
+        a_hy[i] = hrow / HW_; a_hx[i] = hrow - a_hy[i] * HW_;
+        if (hrow >= A_ROWS) a_hy[i] = -1000;            // tail lanes DMA zeros
+        a_col[i] = ((((pc >> 1) ^ seg_s4(hrow)) << 1) | (pc & 1)) * 8;
+    }
+    // dy tile: chunk q -> pixel q / 24, physical chunk q % 24
+    int b_p[BCH], b_col[BCH];
+#pragma unroll
+    for (int j = 0; j < BCH; ++j) {
+        const int q = tid + NT * j, p = q / 24, pc = q - p * 24;
+        const int sp = pc >> 1;
+        const int seg = sp < 8 ? (sp ^ seg_s8(p)) : 8 + ((sp - 8) ^ seg_s4(p));
+        b_p[j] = p;
+        b_col[j] = n0 + (seg * 2 + (pc & 1)) * 8;
+    }
+    auto issue = [&](int slot, int hp) {                  // hp = global half-patch index
+        const int b = hp / hp_per_img, r = hp - b * hp_per_img;
+        const int py0 = (r / hp_w) * 8, px0 = (r % hp_w) * 16;
+        const unsigned dst = lds_base + (unsigned)(slot * STAGE_BYTES) + (unsigned)(wave * 64) * 16u;
+#pragma unroll
+        for (int i = 0; i < A_PASSES; ++i) {
+            if (NT * i + wave * 64 >= A_CHUNKS) continue;
+            const int iy = py0 + a_hy[i] + kh - PAD, ix = px0 + a_hx[i] - PAD;
+            const void* p = zeros;
+            if (iy >= 0 && iy < H && ix >= 0 && ix < W)
+                p = x + (((long)b * H + iy) * W + ix) * g.in_ld + ci0 + a_col[i];
+            glds16(p, dst + (unsigned)(NT * i) * 16u);
+        }
+#pragma unroll
+        for (int j = 0; j < BCH; ++j) {
+            const int py = py0 + (b_p[j] >> 4), px = px0 + (b_p[j] & 15);
+            const void* p = dy + (((long)b * H + py) * W + px) * g.out_ld + b_col[j];
+            glds16(p, dst + (unsigned)A_BYTES + (unsigned)(NT * j) * 16u);
+        }
+    };
+
+    f32x4 acc[KS][2][3];
+#pragma unroll
+    for (int t = 0; t < KS; ++t)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) acc[t][i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int hp_begin = blockIdx.y * hp_per_split;
+    int hp_end = hp_begin + hp_per_split;
+    if (hp_end > hp_total) hp_end = hp_total;
+    const int nsteps = hp_end - hp_begin;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int q4 = fr >> 2, p4 = fr & 3;
+    if (nsteps > 0) issue(0, hp_begin);
+    for (int s = 0; s < nsteps; ++s) {
+        wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (s + 1 < nsteps) issue((s + 1) & 1, hp_begin + s + 1);
+        const unsigned char* bufA = lds + (s & 1) * STAGE_BYTES;
+        const unsigned char* bufB = bufA + A_BYTES;
+#pragma unroll 1
+        for (int ks = 0; ks < 4; ++ks) {                  // 32 pixels per MFMA k-step: patch rows 2ks, 2ks+1
+            // this lane's two 4-pixel blocks: pixels 8*fq + q4 (+4) of the k-step
+            const int pix0 = ks * 32 + 8 * fq + q4, pix1 = pix0 + 4;
+            bf16x8 bfr[3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const int seg = wn * 3 + j;
+                const int g0 = seg < 8 ? (seg ^ seg_s8(pix0)) : 8 + ((seg - 8) ^ seg_s4(pix0));
+                const int g1 = seg < 8 ? (seg ^ seg_s8(pix1)) : 8 + ((seg - 8) ^ seg_s4(pix1));
+                auto lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                    (__attribute__((address_space(3))) bf16x4*)(bufB + pix0 * 384 + (g0 << 5) + p4 * 8));
+                auto hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                    (__attribute__((address_space(3))) bf16x4*)(bufB + pix1 * 384 + (g1 << 5) + p4 * 8));
+                bfr[j] = (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            }
+            // halo rows of the two pixel blocks for tap kw: (row, col + kw)
+            const int hr0 = (pix0 >> 4) * HW_ + (pix0 & 15), hr1 = (pix1 >> 4) * HW_ + (pix1 & 15);
+#pragma unroll
+            for (int kw = 0; kw < KS; ++kw) {
+                const int h0 = hr0 + kw, h1 = hr1 + kw;
+                bf16x8 af[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int seg = wk * 2 + i;
+                    auto lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                        (__attribute__((address_space(3))) bf16x4*)(bufA + h0 * 128 + ((seg ^ seg_s4(h0)) << 5) + p4 * 8));
+                    auto hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                        (__attribute__((address_space(3))) bf16x4*)(bufA + h1 * 128 + ((seg ^ seg_s4(h1)) << 5) + p4 * 8));
+                    af[i] = (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 3; ++j)
+                        acc[kw][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[kw][i][j], 0, 0, 0);
+            }
+        }
+    }
+    // ---- epilogue: f32 atomics (few adders per address: the pixel splits)
+#pragma unroll
+    for (int kw = 0; kw < KS; ++kw)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int n = n0 + wn * 48 + j * 16 + fr;
+            if (n >= g.Cout) continue;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const long k = (long)(kh * KS + kw) * g.Cin + ci0 + wk * 32 + i * 16 + fq * 4 + r;
+                    atomicAdd(dw + k * dw_ld + n, acc[kw][i][j][r]);
+                }
+        }
+}
+
+static bool wgrad_halo_ok(int dtype, const NvaeConvGeom* g, const float* db) {
+    return dtype == NVAE_BF16 && db == nullptr && g->KH == g->KW && (g->KH == 5 || g->KH == 3) && g->stride == 1 &&
+           g->div == 1 && g->pad_t == (g->KH - 1) / 2 && g->pad_l == (g->KW - 1) / 2 && g->Hin == g->Hout &&
+           g->Win == g->Wout && g->Hin % 8 == 0 && g->Win % 16 == 0 && g->Cin % 64 == 0 && g->Cout % 192 == 0 &&
+           (long)g->B * g->Hin * g->Win >= 16384;
+}
+
+static void launch_wgrad_halo(const NvaeConvGeom* g, const void* x, const void* dy, float* dw, int dw_ld,
+                              hipStream_t s) {
+    const int n_tiles = g->Cout / 192, cchunks = g->Cin / 64, KS = g->KH;
+    const int hp_w = g->Win / 16, hp_per_img = (g->Hin / 8) * hp_w, hp_total = g->B * hp_per_img;
+    const int tiles = cchunks * n_tiles * KS;
+    int nsplit = 256 / tiles;                            // one wave of 512-thread workgroups
+    if (nsplit < 1) nsplit = 1;
+    if (nsplit > hp_total / 8) nsplit = hp_total / 8 > 0 ? hp_total / 8 : 1;
+    int hps = cdiv(hp_total, nsplit);
+    nsplit = cdiv(hp_total, hps);
+    dim3 grid(tiles, nsplit);
+    const uint4* zeros = zero_page();
+    if (KS == 5)
+        hipLaunchKernelGGL((k_wgrad_halo<5>), grid, 512, 0, s, *g, (const bf16*)x, (const bf16*)dy, dw, dw_ld, n_tiles,
+                           cchunks, hps, hp_w, hp_per_img, hp_total, zeros);
+    else
+        hipLaunchKernelGGL((k_wgrad_halo<3>), grid, 512, 0, s, *g, (const bf16*)x, (const bf16*)dy, dw, dw_ld, n_tiles,
+                           cchunks, hps, hp_w, hp_per_img, hp_total, zeros);
+}
+
 // Split policy shared by the launcher and the scratch-size query.
 struct WgradPlan { int cfg, tiles, n_tiles, nsplit, mps; bool slab; };
 template <typename T>
@@ -328,6 +517,11 @@ extern "C" int nvae_conv_wgrad(int dtype, const NvaeConvGeom* g, const void* x, 
     NVAE_REQUIRE(g->Cin % ve == 0 && g->in_ld % ve == 0 && g->Cout % ve == 0 && g->out_ld % ve == 0,
                  "conv_wgrad: Cin=%d Cout=%d and their lds must be multiples of %d (use nvae_conv_direct_wgrad)", g->Cin, g->Cout, ve);
     NVAE_REQUIRE(aligned16(x) && aligned16(dy), "conv_wgrad: x/dy must be 16-B aligned");
+    if (wgrad_halo_ok(dtype, g, db)) {
+        launch_wgrad_halo(g, x, dy, dw, dw_ld, (hipStream_t)stream);
+        NVAE_LAUNCH_CHECK("wgrad_halo");
+        return NVAE_OK;
+    }
     DISPATCH_T(dtype, launch_conv_wgrad<T>(g, x, dy, dw, dw_ld, db, scratch, scratch_floats, (hipStream_t)stream);)
     NVAE_LAUNCH_CHECK("conv_wgrad");
     return NVAE_OK;

@@ -64,6 +64,8 @@ CONV_CASES = [
     dict(k=5, cin=192, cout=192, stride=1, up=1, H=8, B=2, bias=False),
     dict(k=5, cin=128, cout=192, stride=1, up=1, H=32, B=16),     # halo-tile kernel (16x16 patches), 5x5
     dict(k=3, cin=128, cout=200, stride=1, up=1, H=16, B=64),     # halo-tile kernel, 3x3, ragged N
+    dict(k=5, cin=128, cout=192, stride=1, up=1, H=32, B=16, bias=False),   # + halo weight-gradient kernel
+    dict(k=3, cin=64, cout=384, stride=1, up=1, H=16, B=64, bias=False),    # halo wgrad, 3x3, two n-tiles
     dict(k=3, cin=1, cout=16, stride=1, up=1, H=8, B=2),          # direct path (stem)
     dict(k=3, cin=16, cout=1, stride=1, up=1, H=8, B=2),          # direct dgrad/wgrad (logit head)
     dict(k=1, cin=20, cout=32, stride=1, up=1, H=4, B=4),         # latent half of the combiner
