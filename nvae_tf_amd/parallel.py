@@ -15,10 +15,12 @@ import torch.distributed as dist
 
 
 class GradReducer:
-    def __init__(self, group: Optional[dist.ProcessGroup] = None, bucket_bytes: int = 64 << 20):
+    def __init__(self, group: Optional[dist.ProcessGroup] = None, bucket_bytes: int = 64 << 20,
+                 force: bool = False):
         assert dist.is_initialized()
         self.group = group
         self.world = dist.get_world_size(group)
+        self.force = force      # issue the collectives even for a single rank (exercises RCCL in tests)
         self.bucket_elems = max(bucket_bytes // 4, 1)
         backend = dist.get_backend(group)
         self.native_avg = backend == "nccl"   # RCCL supports ReduceOp.AVG; gloo does not
@@ -38,7 +40,7 @@ class GradReducer:
         return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op), True
 
     def allreduce_mean_(self, t: torch.Tensor) -> torch.Tensor:
-        if self.world == 1:
+        if self.world == 1 and not self.force:
             return t
         _, need_div = self._allreduce_mean(t, False)
         if need_div:
@@ -47,7 +49,7 @@ class GradReducer:
 
     def allreduce_grads_(self, flat: torch.Tensor) -> torch.Tensor:
         """Average the flat gradient buffer across ranks, bucket by bucket (all in flight at once)."""
-        if self.world == 1:
+        if self.world == 1 and not self.force:
             return flat
         works, need_div = [], False
         for s in self.buckets(flat.numel()):

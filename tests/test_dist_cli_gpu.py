@@ -1,0 +1,65 @@
+"""GPU: (1) the data-parallel step with a real RCCL process group (single rank - one GPU per box):
+hipGraph capture next to an initialised NCCL communicator, ReduceOp.AVG, async bucketed all-reduce
+between graph replays; (2) the train.py command line end to end (train / test / sample modes)."""
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+CFG = dict(n_encoder_channels=16, n_decoder_channels=16, res_cells_per_group=1, n_preprocess_blocks=2,
+           n_preprocess_cells=2, n_latent_per_group=20, n_groups_per_scale=[1, 1], n_postprocess_blocks=2,
+           n_post_process_cells=2)
+
+
+def _model(dev):
+    from nvae_tf_amd.models import NVAE
+    c = CFG
+    return NVAE(c["n_encoder_channels"], c["n_decoder_channels"], c["res_cells_per_group"], c["n_preprocess_blocks"],
+                c["n_preprocess_cells"], c["n_latent_per_group"], 2, c["n_groups_per_scale"], c["n_postprocess_blocks"],
+                c["n_post_process_cells"], 0.01, 2, 10, 1000, True, [8, 32, 32, 1], device=dev, dtype=torch.float32, seed=3)
+
+
+def test_rccl_single_rank_graph_step(lib, dev):
+    import torch.distributed as dist
+    from nvae_tf_amd.parallel import GradReducer
+    from oracle.nvae_oracle import synthetic_batch
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(29600 + os.getpid() % 300)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        x = synthetic_batch(8, seed=2).float()
+        ref, dp = _model(dev), _model(dev)
+        dp.ps.params.copy_(ref.ps.params); dp.ps.state.copy_(ref.ps.state)
+        dp.reducer = GradReducer(bucket_bytes=1 << 20, force=True)       # several buckets
+        dist.broadcast(dp.ps.params, 0)
+        dp.capture_train_step(x.shape, warmup=1)
+        dp.ps.params.copy_(ref.ps.params); dp.ps.state.copy_(ref.ps.state)
+        dp.ps.adam_m.zero_(); dp.ps.adam_u.zero_(); dp.rng_counter.zero_(); ref.rng_counter.zero_()
+        dp.steps = ref.steps = 50
+        dp.opt_iterations = ref.opt_iterations = 0
+        for _ in range(3):
+            o_ref = ref.train_step(x)
+            o_dp = dp.train_step_graphed(x)
+        torch.cuda.synchronize()
+        assert abs(float(o_ref["loss"]) - float(o_dp["loss"])) / abs(float(o_ref["loss"])) < 1e-4
+    finally:
+        dist.destroy_process_group()
+
+
+def test_train_cli_modes(lib, dev, tmp_path, capsys):
+    from nvae_tf_amd import train
+    common = ["--synthetic", "--batch_size", "16", "--n_encoder_channels", "16", "--n_decoder_channels", "16",
+              "--n_groups_per_scale", "1", "1", "--n_preprocess_cells", "2", "--n_postprocess_cells", "2",
+              "--model_save_dir", str(tmp_path / "models"), "--sample_dir", str(tmp_path / "results"),
+              "--dtype", "bf16", "--debug", "--step_based_warmup"]
+    train.main(train.parse_args(["--mode", "train", "--epochs", "2", "--model_save_frequency", "1",
+                                 "--sample_frequency", "1"] + common))
+    assert (tmp_path / "models" / "epoch_final.pt").exists() and (tmp_path / "models" / "epoch_1.pt").exists()
+    assert len(list((tmp_path / "results" / "epoch_0").iterdir())) == 16
+    train.main(train.parse_args(["--mode", "test", "--epochs", "2", "--resume_from", "1", "--binary_eval"] + common))
+    out = capsys.readouterr().out
+    assert "Negative log likelihood" in out
+    train.main(train.parse_args(["--mode", "sample", "--epochs", "2", "--resume_from", "1", "--n_samples", "16"] + common))
+    for t in ("t_0.7", "t_0.8", "t_0.9", "t_1.0"):
+        assert len(list((tmp_path / "results" / t).iterdir())) == 16
