@@ -114,19 +114,22 @@ int nvae_bn_finalize(const float* partials, long rows, int C, const float* gamma
 int nvae_bn_finalize_s(const float* partials, int S, long rows, int C, const float* gamma,
                        const float* beta, float* running_mean, float* running_var, float momentum,
                        float eps, float* scale, float* shift, float* mean, float* invstd, void* stream);
+/* inference mode: scale/shift from the moving statistics; mean/invstd (may both be NULL) receive the
+ * moving mean and 1/sqrt(moving_var + eps) for a backward pass through the frozen layer.          */
 int nvae_bn_eval_prepare(const float* gamma, const float* beta, const float* running_mean,
                          const float* running_var, int C, float eps, float* scale, float* shift,
-                         void* stream);
+                         float* mean, float* invstd, void* stream);
 int nvae_bn_apply(int dtype, const void* x, void* y, long rows, int C, const float* scale,
                   const float* shift, int act, void* stream);
 /* partials[S][2][C] <- per-split (sum dpre, sum dpre*x); dpre = dy * act'(scale*x + shift).      */
 int nvae_bn_bwd_reduce(int dtype, const void* x, const void* dy, long rows, int C, const float* scale,
                        const float* shift, int act, float* partials, void* stream);
 /* dgamma += sum dpre*xhat, dbeta += sum dpre; k0k1[2][C] = coefficients of
- * dx = scale*dpre + k1*x + k0 (the batch-statistics terms of the BN gradient).                   */
+ * dx = scale*dpre + k1*x + k0 (the batch-statistics terms of the BN gradient; zero when `frozen`,
+ * i.e. the layer normalised with moving statistics).                                            */
 int nvae_bn_bwd_finalize(const float* partials, long rows, int C, const float* scale,
                          const float* mean, const float* invstd, float* dgamma, float* dbeta,
-                         float* k0k1, void* stream);
+                         float* k0k1, int frozen, void* stream);
 int nvae_bn_bwd_apply(int dtype, const void* x, const void* dy, void* dx, long rows, int C,
                       const float* scale, const float* shift, const float* k0k1, int act,
                       int accumulate, void* stream);

@@ -204,19 +204,22 @@ extern "C" int nvae_bn_finalize_s(const float* partials, int S, long rows, int C
 }
 
 __global__ void k_bn_eval_prepare(const float* gamma, const float* beta, const float* rm,
-                                  const float* rv, int C, float eps, float* scale, float* shift) {
+                                  const float* rv, int C, float eps, float* scale, float* shift,
+                                  float* mean, float* invstd) {
     int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= C) return;
-    float sc = gamma[c] * rsqrtf(rv[c] + eps);
+    float is = rsqrtf(rv[c] + eps);
+    float sc = gamma[c] * is;
     scale[c] = sc;
     shift[c] = beta[c] - rm[c] * sc;
+    if (mean) { mean[c] = rm[c]; invstd[c] = is; }
 }
 
 extern "C" int nvae_bn_eval_prepare(const float* gamma, const float* beta, const float* rm,
                                     const float* rv, int C, float eps, float* scale, float* shift,
-                                    void* stream) {
-    NVAE_REQUIRE(C > 0, "bn_eval_prepare: bad C");
-    hipLaunchKernelGGL(k_bn_eval_prepare, cdiv(C, 256), 256, 0, (hipStream_t)stream, gamma, beta, rm, rv, C, eps, scale, shift);
+                                    float* mean, float* invstd, void* stream) {
+    NVAE_REQUIRE(C > 0 && ((mean == nullptr) == (invstd == nullptr)), "bn_eval_prepare: bad args");
+    hipLaunchKernelGGL(k_bn_eval_prepare, cdiv(C, 256), 256, 0, (hipStream_t)stream, gamma, beta, rm, rv, C, eps, scale, shift, mean, invstd);
     NVAE_LAUNCH_CHECK("bn_eval_prepare");
     return NVAE_OK;
 }
@@ -276,7 +279,7 @@ extern "C" int nvae_bn_bwd_reduce(int dtype, const void* x, const void* dy, long
 __global__ void k_bn_bwd_finalize(const float* __restrict__ partials, int S, float inv_n, int C,
                                   const float* __restrict__ scale, const float* __restrict__ mean,
                                   const float* __restrict__ invstd, float* dgamma, float* dbeta,
-                                  float* __restrict__ k0k1) {
+                                  float* __restrict__ k0k1, int frozen) {
     int c;
     float s1, s2;
     if (!slab_sum32(partials, S, C, c, s1, s2)) return;
@@ -284,18 +287,19 @@ __global__ void k_bn_bwd_finalize(const float* __restrict__ partials, int S, flo
     const float dg = is * (s2 - m * s1);
     dgamma[c] += dg;
     dbeta[c] += s1;
-    const float k1 = -sc * dg * is * inv_n;
-    k0k1[c] = -sc * s1 * inv_n - k1 * m;
+    // frozen (moving) statistics do not depend on the batch: dx = scale * dpre only
+    const float k1 = frozen ? 0.f : -sc * dg * is * inv_n;
+    k0k1[c] = frozen ? 0.f : -sc * s1 * inv_n - k1 * m;
     k0k1[C + c] = k1;
 }
 
 extern "C" int nvae_bn_bwd_finalize(const float* partials, long rows, int C, const float* scale,
                                     const float* mean, const float* invstd, float* dgamma, float* dbeta,
-                                    float* k0k1, void* stream) {
+                                    float* k0k1, int frozen, void* stream) {
     NVAE_REQUIRE(rows > 0 && C > 0 && partials && k0k1, "bn_bwd_finalize: bad args");
     const int S = nvae_reduce_splits(rows, C);
     hipLaunchKernelGGL(k_bn_bwd_finalize, cdiv(C, 32), 256, 0, (hipStream_t)stream, partials, S,
-                       1.0f / (float)rows, C, scale, mean, invstd, dgamma, dbeta, k0k1);
+                       1.0f / (float)rows, C, scale, mean, invstd, dgamma, dbeta, k0k1, frozen);
     NVAE_LAUNCH_CHECK("bn_bwd_finalize");
     return NVAE_OK;
 }

@@ -171,7 +171,7 @@ __global__ __launch_bounds__(WM* WN * 64) void k_conv_gemm2(
     static_assert(BKC == 8 || BKC == 16, "row width");
     static_assert(STAGES * STAGE * 16 >= WM * WN * 16 * (BN / WN + 4) * 4, "epilogue staging must fit in the ring");
     static_assert(STAGES * STAGE * 16 >= WM * BN * 2 * 4, "stats scratch must fit in the ring");
-    static_assert(STAGES == 2 || STAGES == 3, "ring depth");
+    static_assert(STAGES >= 2 && STAGES <= 4, "ring depth");
     __shared__ uint4 lds[STAGES * STAGE];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -253,10 +253,14 @@ __global__ __launch_bounds__(WM* WN * 64) void k_conv_gemm2(
     const int nk = (K + BKE - 1) / BKE;
     const int fr = lane & 15, fq = lane >> 4;
     issue(0);
-    if (STAGES == 3 && nk > 1) issue(1);
+    if (STAGES >= 3 && nk > 1) issue(1);
+    if (STAGES >= 4 && nk > 2) issue(2);
     int cur = 0;
     for (int t = 0; t < nk; ++t) {
-        if (STAGES == 3 && t + 1 < nk) wait_vmcnt<NLOAD>();
+        // stage t must have landed; up to STAGES-2 younger stages may stay in flight
+        const int younger = nk - 1 - t;
+        if (STAGES >= 4 && younger >= 2) wait_vmcnt<2 * NLOAD>();
+        else if (STAGES >= 3 && younger >= 1) wait_vmcnt<NLOAD>();
         else wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");

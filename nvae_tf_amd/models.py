@@ -85,6 +85,10 @@ class NVAE:
         self._buf: Dict[int, Dict[str, torch.Tensor]] = {}
         self._plan = None
         self.overlap_wgrad = True   # weight-gradient kernels run on a side stream, joined before Adamax
+        # the reference never passes training=True, which under TF-2.3 Keras most likely
+        # leaves BatchNorm in inference mode and SpectralNormalization a no-op while training.
+        # tf_literal=True reproduces that; the default is the author-intended training semantics.
+        self.tf_literal = False
         self._side = None
 
     # ------------------------------------------------------------------ helpers
@@ -226,10 +230,10 @@ class NVAE:
         B = x.shape[0]
         buf = self._buffers(B)
         ps.begin_step()
-        ps.prepare_weights(spectral_norm=spectral_norm)
+        ps.prepare_weights(spectral_norm=spectral_norm and not self.tf_literal)
         if self.overlap_wgrad and self._side is None and self.device.type == "cuda":
             self._side = torch.cuda.Stream(device=self.device)
-        ctx = Ctx(ps, self.dtype, training=True, record=True,
+        ctx = Ctx(ps, self.dtype, training=not self.tf_literal, record=True,
                   side_stream=self._side if self.overlap_wgrad else None)
         self._bn_loss = ctx.zeros_f32(1)
         nb = len(ps.bn_loss_layers)

@@ -290,11 +290,11 @@ def bn_act(ctx: Ctx, x: Var, bn, act: int = L.ACT_NONE) -> Var:
         call("nvae_bn_finalize", ptr(partials), rows, Cc, gamma, beta, rm, rv, BN_MOMENTUM, BN_EPS, scale,
              shift, mean, invstd)
     else:
-        call("nvae_bn_eval_prepare", gamma, beta, rm, rv, Cc, BN_EPS, scale, shift)
+        call("nvae_bn_eval_prepare", gamma, beta, rm, rv, Cc, BN_EPS, scale, shift, mean, invstd)
     y = Var(ctx.empty(x.t.shape), x.needs_grad)
     call("nvae_bn_apply", ctx.dt, ptr(x.t), ptr(y.t), rows, Cc, scale, shift, act)
     if ctx.record:
-        assert ctx.training, "backward through inference-mode BN is not on the path"
+        frozen = 0 if ctx.training else 1      # tf_literal: backward through moving-statistics BN
 
         def bwd():
             dgamma = ptr(ps.grads) + bn.gamma.off * 4
@@ -302,7 +302,7 @@ def bn_act(ctx: Ctx, x: Var, bn, act: int = L.ACT_NONE) -> Var:
             part = ctx.empty((S, 2, Cc), torch.float32)
             k0k1 = ctx.empty((2, Cc), torch.float32)
             call("nvae_bn_bwd_reduce", ctx.dt, ptr(x.t), ptr(y.g), rows, Cc, scale, shift, act, ptr(part))
-            call("nvae_bn_bwd_finalize", ptr(part), rows, Cc, scale, mean, invstd, dgamma, dbeta, ptr(k0k1))
+            call("nvae_bn_bwd_finalize", ptr(part), rows, Cc, scale, mean, invstd, dgamma, dbeta, ptr(k0k1), frozen)
             if x.needs_grad:
                 g, acc = ctx.grad_of(x)
                 call("nvae_bn_bwd_apply", ctx.dt, ptr(x.t), ptr(y.g), ptr(g), rows, Cc, scale, shift,

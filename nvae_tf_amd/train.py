@@ -115,6 +115,7 @@ def main(args):
                  input_shape=[args.batch_size // world, 32, 32, 1], device=f"cuda:{local}",
                  dtype=torch.bfloat16 if args.dtype == "bf16" else torch.float32, seed=args.seed + rank,
                  lr_decay_steps=args.epochs * batches_per_epoch)
+    model.tf_literal = args.tf_literal
     if world > 1:
         import torch.distributed as dist
         model.reducer = parallel.GradReducer()
@@ -170,6 +171,9 @@ def parse_args(argv=None):
     p.add_argument("--data_dir", type=str, default=None, help="directory with mnist.npz or the IDX files")
     p.add_argument("--synthetic", action="store_true", help="random MNIST-shaped data (no files needed)")
     p.add_argument("--no_graph", action="store_true", help="launch eagerly instead of replaying hipGraphs")
+    p.add_argument("--tf_literal", action="store_true",
+                   help="reference-literal semantics (SURVEY Q1): BatchNorm with moving statistics and no "
+                        "spectral normalisation during training")
     return p.parse_args(argv)
 
 

@@ -591,11 +591,12 @@ class OracleNVAE:
                 self.opt_u[k] = torch.maximum(b2 * self.opt_u[k], g.abs())
                 p.sub_(lr / (1 - b1 ** t) * self.opt_m[k] / (self.opt_u[k] + eps))
 
-    def train_step(self, x, eps_list, decay_steps=None, spectral_norm=True):
-        """NVAE.train_step, models.py:100-135 with training-mode semantics (Q1)."""
-        if spectral_norm:
+    def train_step(self, x, eps_list, decay_steps=None, spectral_norm=True, tf_literal=False):
+        """NVAE.train_step, models.py:100-135 with training-mode semantics (Q1); tf_literal=True is the
+        reference's literal behaviour (BN moving statistics, no spectral normalisation)."""
+        if spectral_norm and not tf_literal:
             self.spectral_norm_step()
-        out = self.loss(x, eps_list, training=True)
+        out = self.loss(x, eps_list, training=not tf_literal)
         names = list(self.s.params.keys())
         grads = torch.autograd.grad(out["loss"], [self.s.params[k] for k in names],
                                     allow_unused=True)

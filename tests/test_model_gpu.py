@@ -165,3 +165,49 @@ def test_training_reduces_loss(lib, dev):
         last = v
     print("loss", first, "->", last)
     assert last < first - 20
+
+
+def test_tf_literal_train_step_parity(lib, dev):
+    """the reference-literal mode (moving-statistics BN, no spectral norm while training),
+    including the backward pass through the frozen BatchNorm layers."""
+    orc, model, x, eps = build_pair(dev, torch.float32)
+    g = torch.Generator().manual_seed(5)
+    for k in orc.s.state:
+        if k.endswith(".rm"):
+            orc.s.state[k] = torch.randn(orc.s.state[k].shape, generator=g, dtype=torch.float64) * 0.1
+        elif k.endswith(".rv"):
+            orc.s.state[k] = torch.rand(orc.s.state[k].shape, generator=g, dtype=torch.float64) + 0.5
+    model.ps.load_named(orc.s.params, orc.s.state)
+    state_before = model.ps.state.clone()
+    model.tf_literal = True
+    orc.steps = model.steps = 100
+    out_o = orc.train_step(x, eps, decay_steps=1000, tf_literal=True)
+    out = model.train_step(x.float(), [e.float() for e in eps])
+    torch.cuda.synchronize()
+    assert abs(float(out["loss"]) - float(out_o["loss"])) / abs(float(out_o["loss"])) < 1e-3
+    assert rel(out["kl_per_group"], out_o["kl_per_group"]) < 3e-3
+    go = torch.cat([out_o["grads"][k].reshape(-1) for k in out_o["grads"]])
+    gp = torch.cat([model.ps.get_grad(k).double().cpu().reshape(-1) for k in out_o["grads"]])
+    assert float((go * gp).sum() / (go.norm() * gp.norm())) > 0.99999
+    for k in ("enc.g0.c0.bn1.gamma", "dec.g1.c0.bn3.beta", "post.cell0.bn2.gamma", "enc.g1.c0.conv1.w"):
+        assert rel(model.ps.get_grad(k), out_o["grads"][k]) < 5e-3, k
+    assert torch.equal(model.ps.state, state_before)      # neither moving statistics nor SN state move
+
+
+def test_c1_architecture_parity(lib, dev):
+    """BASELINE.json configs[0] architecture (32 channels, groups [1,1], 1 cell, 2 x 3 pre/post cells;
+    17 243 405 parameters) at batch 4, f32 HIP path vs the fp64 oracle."""
+    cfg = dict(CFG, n_encoder_channels=32, n_decoder_channels=32, n_preprocess_cells=3, n_post_process_cells=3,
+               n_groups_per_scale=[1, 1])
+    orc, model, x, eps = build_pair(dev, torch.float32, cfg)
+    assert model.n_trainable() == 17243405
+    orc.steps = model.steps = 100
+    out_o = orc.train_step(x, eps, decay_steps=1000)
+    out = model.train_step(x.float(), [e.float() for e in eps])
+    torch.cuda.synchronize()
+    assert abs(float(out["loss"]) - float(out_o["loss"])) / abs(float(out_o["loss"])) < 1e-3
+    assert rel(out["reconstruction_loss"], out_o["reconstruction_loss"]) < 1e-3
+    assert rel(out["kl_per_group"], out_o["kl_per_group"]) < 3e-3
+    go = torch.cat([out_o["grads"][k].reshape(-1) for k in out_o["grads"]])
+    gp = torch.cat([model.ps.get_grad(k).double().cpu().reshape(-1) for k in out_o["grads"]])
+    assert float((go * gp).sum() / (go.norm() * gp.norm())) > 0.99999
