@@ -114,6 +114,13 @@ int nvae_bn_finalize(const float* partials, long rows, int C, const float* gamma
 int nvae_bn_finalize_s(const float* partials, int S, long rows, int C, const float* gamma,
                        const float* beta, float* running_mean, float* running_var, float momentum,
                        float eps, float* scale, float* shift, float* mean, float* invstd, void* stream);
+/* nvae_bn_stats + nvae_bn_finalize in ONE launch: the last workgroup of each 64-channel strip sums the
+ * slabs and writes the coefficients ("last arriver finalizes", csrc/bn_fin.h).  counters: at least
+ * ceil(C/64) ints, zero before the first use; the kernel leaves them zero again.                  */
+int nvae_bn_stats_fin(int dtype, const void* x, long rows, int C, float* partials, int* counters,
+                      const float* gamma, const float* beta, float* running_mean, float* running_var,
+                      float momentum, float eps, float* scale, float* shift, float* mean,
+                      float* invstd, void* stream);
 /* inference mode: scale/shift from the moving statistics; mean/invstd (may both be NULL) receive the
  * moving mean and 1/sqrt(moving_var + eps) for a backward pass through the frozen layer.          */
 int nvae_bn_eval_prepare(const float* gamma, const float* beta, const float* running_mean,
@@ -130,6 +137,11 @@ int nvae_bn_bwd_reduce(int dtype, const void* x, const void* dy, long rows, int 
 int nvae_bn_bwd_finalize(const float* partials, long rows, int C, const float* scale,
                          const float* mean, const float* invstd, float* dgamma, float* dbeta,
                          float* k0k1, int frozen, void* stream);
+/* nvae_bn_bwd_reduce + nvae_bn_bwd_finalize in ONE launch (counters as for nvae_bn_stats_fin).    */
+int nvae_bn_bwd_reduce_fin(int dtype, const void* x, const void* dy, long rows, int C,
+                           const float* scale, const float* shift, const float* mean,
+                           const float* invstd, int act, float* partials, int* counters,
+                           float* dgamma, float* dbeta, float* k0k1, int frozen, void* stream);
 int nvae_bn_bwd_apply(int dtype, const void* x, const void* dy, void* dx, long rows, int C,
                       const float* scale, const float* shift, const float* k0k1, int act,
                       int accumulate, void* stream);

@@ -8,6 +8,7 @@
 // MI355X, 1024 workgroups adding into the same 2C addresses cost 250-300 us per call (same-address
 // f32 atomics serialise at the memory side), 30x the streaming time of the tensor.
 #include "common.h"
+#include "bn_fin.h"
 
 #define RED_THREADS 256
 #define MAX_SPLITS 128
@@ -21,7 +22,7 @@ template <typename T, int MODE>
 __global__ __launch_bounds__(RED_THREADS) void k_stripreduce(
     const T* __restrict__ x, const T* __restrict__ dy, long rows_per_group, int C, int ld,
     int rows_per_block, const float* __restrict__ scale, const float* __restrict__ shift, int act,
-    float* out) {
+    float* out, BnFinArgs fin) {
     constexpr int NQ = (MODE <= 1) ? 2 : 1;
     // thread groups of 8 channels per strip, padded to a power of two (1, 2, 4 or 8) so that lanes
     // holding the same channels are a fixed power-of-two apart
@@ -97,10 +98,17 @@ __global__ __launch_bounds__(RED_THREADS) void k_stripreduce(
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 float v = sm[0][tg][q * 8 + j] + sm[1][tg][q * 8 + j] + sm[2][tg][q * 8 + j] + sm[3][tg][q * 8 + j];
-                if (MODE <= 1) out[((long)blockIdx.y * NQ + q) * C + c0 + j] = v;      // slab [S][NQ][C]
+                if (MODE <= 1) bn_store_partial(out + ((long)blockIdx.y * NQ + q) * C + c0 + j, v);   // slab [S][NQ][C]
                 else if (MODE == 4) atomicAdd(out + c0 + j, v);
                 else out[grp * C + c0 + j] = v;                                       // [B][C], S == 1
             }
+    }
+    if (MODE <= 1) {
+        // fused finalize: the last of this strip's gridDim.y workgroups turns the slabs into coefficients
+        if (fin.counter == nullptr) return;
+        if (!bn_last_arriver(fin.counter + blockIdx.x, (int)gridDim.y)) return;
+        if (MODE == 0) bn_fin_fwd(fin, out, (int)gridDim.y, C, blockIdx.x * 64, 1);
+        else bn_fin_bwd(fin, out, (int)gridDim.y, C, blockIdx.x * 64, 1);
     }
 }
 
@@ -121,11 +129,14 @@ extern "C" int nvae_reduce_splits(long rows, int C) {
 
 template <typename T, int MODE>
 static void launch_strip(const T* x, const T* dy, long groups, long rows, int C, int ld, int S,
-                         const float* scale, const float* shift, int act, float* out, hipStream_t s) {
+                         const float* scale, const float* shift, int act, float* out, hipStream_t s,
+                         const BnFinArgs* fin = nullptr) {
     long rpb = (rows + S - 1) / S;
     dim3 grid((C + 63) / 64, S, (unsigned)groups);
+    BnFinArgs f{};
+    if (fin) f = *fin;
     hipLaunchKernelGGL((k_stripreduce<T, MODE>), grid, RED_THREADS, 0, s, x, dy, rows, C, ld, (int)rpb,
-                       scale, shift, act, out);
+                       scale, shift, act, out, f);
 }
 
 static int check_c(const char* who, int C) {
@@ -142,34 +153,13 @@ extern "C" int nvae_bn_stats(int dtype, const void* x, long rows, int C, float* 
     return NVAE_OK;
 }
 
-// Sum the [S][2][C] slab for 32 channels per workgroup: 8 lanes-groups walk S in parallel, one LDS hop.
-// Returns true (with s1, s2 valid) for the 32 threads that own a channel.
-__device__ __forceinline__ bool slab_sum32(const float* __restrict__ partials, int S, int C, int& c,
-                                           float& s1, float& s2) {
-    __shared__ float sm[8][32][2];
-    const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
-    c = blockIdx.x * 32 + cl;
-    s1 = 0.f; s2 = 0.f;
-    if (c < C)
-        for (int s = sl; s < S; s += 8) {
-            s1 += partials[(long)(2 * s) * C + c];
-            s2 += partials[(long)(2 * s + 1) * C + c];
-        }
-    sm[sl][cl][0] = s1; sm[sl][cl][1] = s2;
-    __syncthreads();
-    if (sl != 0 || c >= C) return false;
-#pragma unroll
-    for (int k = 1; k < 8; ++k) { s1 += sm[k][cl][0]; s2 += sm[k][cl][1]; }
-    return true;
-}
-
 __global__ void k_bn_finalize(const float* __restrict__ partials, int S, float inv_n, int C,
                               const float* __restrict__ gamma, const float* __restrict__ beta,
                               float* rm, float* rv, float momentum, float eps, float* scale,
                               float* shift, float* mean, float* invstd) {
     int c;
     float s1, s2;
-    if (!slab_sum32(partials, S, C, c, s1, s2)) return;
+    if (!bn_slab_sum64(partials, S, C, blockIdx.x * 64, c, s1, s2)) return;
     float m = s1 * inv_n;
     float var = fmaxf(s2 * inv_n - m * m, 0.f);
     float is = rsqrtf(var + eps);
@@ -187,7 +177,7 @@ extern "C" int nvae_bn_finalize(const float* partials, long rows, int C, const f
                                 float* scale, float* shift, float* mean, float* invstd, void* stream) {
     NVAE_REQUIRE(rows > 0 && C > 0, "bn_finalize: bad shape");
     const int S = nvae_reduce_splits(rows, C);
-    hipLaunchKernelGGL(k_bn_finalize, cdiv(C, 32), 256, 0, (hipStream_t)stream, partials, S, 1.0f / (float)rows,
+    hipLaunchKernelGGL(k_bn_finalize, cdiv(C, 64), 256, 0, (hipStream_t)stream, partials, S, 1.0f / (float)rows,
                        C, gamma, beta, rm, rv, momentum, eps, scale, shift, mean, invstd);
     NVAE_LAUNCH_CHECK("bn_finalize");
     return NVAE_OK;
@@ -197,9 +187,26 @@ extern "C" int nvae_bn_finalize_s(const float* partials, int S, long rows, int C
                                   const float* beta, float* rm, float* rv, float momentum, float eps,
                                   float* scale, float* shift, float* mean, float* invstd, void* stream) {
     NVAE_REQUIRE(rows > 0 && C > 0 && S > 0, "bn_finalize_s: bad shape");
-    hipLaunchKernelGGL(k_bn_finalize, cdiv(C, 32), 256, 0, (hipStream_t)stream, partials, S, 1.0f / (float)rows,
+    hipLaunchKernelGGL(k_bn_finalize, cdiv(C, 64), 256, 0, (hipStream_t)stream, partials, S, 1.0f / (float)rows,
                        C, gamma, beta, rm, rv, momentum, eps, scale, shift, mean, invstd);
     NVAE_LAUNCH_CHECK("bn_finalize_s");
+    return NVAE_OK;
+}
+
+// Statistics + finalize in one launch (bn_fin.h).  `counters`: >= ceil(C/64) zero-initialised ints.
+extern "C" int nvae_bn_stats_fin(int dtype, const void* x, long rows, int C, float* partials, int* counters,
+                                 const float* gamma, const float* beta, float* rm, float* rv,
+                                 float momentum, float eps, float* scale, float* shift, float* mean,
+                                 float* invstd, void* stream) {
+    if (int e = check_c("bn_stats_fin", C)) return e;
+    NVAE_REQUIRE(rows > 0 && aligned16(x) && partials && counters && gamma && beta && rm && rv && scale && shift && mean && invstd,
+                 "bn_stats_fin: bad rows/alignment/null argument");
+    const int S = nvae_reduce_splits(rows, C);
+    BnFinArgs f{};
+    f.counter = counters; f.inv_n = 1.0f / (float)rows; f.gamma = gamma; f.beta = beta; f.rm = rm; f.rv = rv;
+    f.momentum = momentum; f.eps = eps; f.scale = scale; f.shift = shift; f.mean = mean; f.invstd = invstd;
+    DISPATCH_T(dtype, launch_strip<T, 0>((const T*)x, nullptr, 1, rows, C, C, S, nullptr, nullptr, 0, partials, (hipStream_t)stream, &f);)
+    NVAE_LAUNCH_CHECK("bn_stats_fin");
     return NVAE_OK;
 }
 
@@ -282,7 +289,7 @@ __global__ void k_bn_bwd_finalize(const float* __restrict__ partials, int S, flo
                                   float* __restrict__ k0k1, int frozen) {
     int c;
     float s1, s2;
-    if (!slab_sum32(partials, S, C, c, s1, s2)) return;
+    if (!bn_slab_sum64(partials, S, C, blockIdx.x * 64, c, s1, s2)) return;
     const float m = mean[c], is = invstd[c], sc = scale[c];
     const float dg = is * (s2 - m * s1);
     dgamma[c] += dg;
@@ -298,9 +305,27 @@ extern "C" int nvae_bn_bwd_finalize(const float* partials, long rows, int C, con
                                     float* k0k1, int frozen, void* stream) {
     NVAE_REQUIRE(rows > 0 && C > 0 && partials && k0k1, "bn_bwd_finalize: bad args");
     const int S = nvae_reduce_splits(rows, C);
-    hipLaunchKernelGGL(k_bn_bwd_finalize, cdiv(C, 32), 256, 0, (hipStream_t)stream, partials, S,
+    hipLaunchKernelGGL(k_bn_bwd_finalize, cdiv(C, 64), 256, 0, (hipStream_t)stream, partials, S,
                        1.0f / (float)rows, C, scale, mean, invstd, dgamma, dbeta, k0k1, frozen);
     NVAE_LAUNCH_CHECK("bn_bwd_finalize");
+    return NVAE_OK;
+}
+
+// Backward reduction + finalize in one launch (bn_fin.h).
+extern "C" int nvae_bn_bwd_reduce_fin(int dtype, const void* x, const void* dy, long rows, int C,
+                                      const float* scale, const float* shift, const float* mean,
+                                      const float* invstd, int act, float* partials, int* counters,
+                                      float* dgamma, float* dbeta, float* k0k1, int frozen, void* stream) {
+    if (int e = check_c("bn_bwd_reduce_fin", C)) return e;
+    NVAE_REQUIRE(rows > 0 && aligned16(x) && aligned16(dy) && partials && counters && scale && shift && mean && invstd && dgamma && dbeta && k0k1,
+                 "bn_bwd_reduce_fin: bad rows/alignment/null argument");
+    const int S = nvae_reduce_splits(rows, C);
+    BnFinArgs f{};
+    f.counter = counters; f.inv_n = 1.0f / (float)rows;
+    f.scale = (float*)scale; f.mean = (float*)mean; f.invstd = (float*)invstd;
+    f.dgamma = dgamma; f.dbeta = dbeta; f.k0k1 = k0k1; f.frozen = frozen;
+    DISPATCH_T(dtype, launch_strip<T, 1>((const T*)x, (const T*)dy, 1, rows, C, C, S, scale, shift, act, partials, (hipStream_t)stream, &f);)
+    NVAE_LAUNCH_CHECK("bn_bwd_reduce_fin");
     return NVAE_OK;
 }
 

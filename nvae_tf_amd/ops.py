@@ -35,6 +35,9 @@ class Var:
         return self.t.shape
 
 
+FUSED_FIN = os.environ.get("NVAE_BN_FUSED_FIN", "1") != "0"
+
+
 class Ctx:
     """Per-step execution context: dtype, mode, tape, and the per-step zeroed f32 scratch pool."""
 
@@ -55,6 +58,7 @@ class Ctx:
         self.tape: List[Callable[[], None]] = []
         self.dev = ps.params.device
         self.zero_pool = ps.zero_pool
+        self._counters = None
         self.zero_cursor = ps.zero_reserved
 
     # ---- memory -------------------------------------------------------------------------
@@ -69,6 +73,13 @@ class Ctx:
         out = self.zero_pool[self.zero_cursor:self.zero_cursor + n]
         self.zero_cursor += n_al
         return out
+
+    def counters(self) -> int:
+        """Arrival counters of the fused BatchNorm finalizes (csrc/bn_fin.h): zero at rest, shared by
+        all launches of the main stream (they are serialised there)."""
+        if self._counters is None:
+            self._counters = self.zeros_f32(256)
+        return ptr(self._counters)
 
     def grad_of(self, v: Var) -> Tuple[torch.Tensor, int]:
         """Gradient buffer of v and whether the next writer must accumulate into it."""
@@ -286,9 +297,13 @@ def bn_act(ctx: Ctx, x: Var, bn, act: int = L.ACT_NONE) -> Var:
              shift, mean, invstd)
     elif ctx.training:
         partials = ctx.empty((S, 2, Cc), torch.float32)
-        call("nvae_bn_stats", ctx.dt, ptr(x.t), rows, Cc, ptr(partials))
-        call("nvae_bn_finalize", ptr(partials), rows, Cc, gamma, beta, rm, rv, BN_MOMENTUM, BN_EPS, scale,
-             shift, mean, invstd)
+        if FUSED_FIN:
+            call("nvae_bn_stats_fin", ctx.dt, ptr(x.t), rows, Cc, ptr(partials), ctx.counters(), gamma, beta, rm,
+                 rv, BN_MOMENTUM, BN_EPS, scale, shift, mean, invstd)
+        else:
+            call("nvae_bn_stats", ctx.dt, ptr(x.t), rows, Cc, ptr(partials))
+            call("nvae_bn_finalize", ptr(partials), rows, Cc, gamma, beta, rm, rv, BN_MOMENTUM, BN_EPS, scale,
+                 shift, mean, invstd)
     else:
         call("nvae_bn_eval_prepare", gamma, beta, rm, rv, Cc, BN_EPS, scale, shift, mean, invstd)
     y = Var(ctx.empty(x.t.shape), x.needs_grad)
@@ -301,8 +316,13 @@ def bn_act(ctx: Ctx, x: Var, bn, act: int = L.ACT_NONE) -> Var:
             dbeta = ptr(ps.grads) + bn.beta.off * 4
             part = ctx.empty((S, 2, Cc), torch.float32)
             k0k1 = ctx.empty((2, Cc), torch.float32)
-            call("nvae_bn_bwd_reduce", ctx.dt, ptr(x.t), ptr(y.g), rows, Cc, scale, shift, act, ptr(part))
-            call("nvae_bn_bwd_finalize", ptr(part), rows, Cc, scale, mean, invstd, dgamma, dbeta, ptr(k0k1), frozen)
+            if FUSED_FIN:
+                call("nvae_bn_bwd_reduce_fin", ctx.dt, ptr(x.t), ptr(y.g), rows, Cc, scale, shift, mean, invstd,
+                     act, ptr(part), ctx.counters(), dgamma, dbeta, ptr(k0k1), frozen)
+            else:
+                call("nvae_bn_bwd_reduce", ctx.dt, ptr(x.t), ptr(y.g), rows, Cc, scale, shift, act, ptr(part))
+                call("nvae_bn_bwd_finalize", ptr(part), rows, Cc, scale, mean, invstd, dgamma, dbeta, ptr(k0k1),
+                     frozen)
             if x.needs_grad:
                 g, acc = ctx.grad_of(x)
                 call("nvae_bn_bwd_apply", ctx.dt, ptr(x.t), ptr(y.g), ptr(g), rows, Cc, scale, shift,

@@ -229,6 +229,49 @@ def test_bn_act(lib, dev, dtype, act, shape):
     assert rel_err(y2.t, pre * torch.sigmoid(pre) if act else pre) < tol
 
 
+@pytest.mark.parametrize("shape", [(128, 8, 8, 128), (64, 4, 4, 1536), (16, 32, 32, 40)])
+def test_bn_fused_finalize_matches_two_launch(lib, dev, shape):
+    """"Last arriver finalizes" (csrc/bn_fin.h) against the separate reduce + finalize launches, at
+    shapes with up to 128 row splits, re-using one counter buffer across launches."""
+    from nvae_tf_amd._lib import call, ptr
+    g = torch.Generator().manual_seed(3)
+    Cc = shape[3]
+    rows = shape[0] * shape[1] * shape[2]
+    x = (torch.randn(shape, generator=g) * 1.3 + 0.2).to(dev, torch.bfloat16)
+    dy = torch.randn(shape, generator=g).to(dev, torch.bfloat16)
+    gamma = (torch.rand(Cc, generator=g) + 0.5).to(dev)
+    beta = torch.randn(Cc, generator=g).to(dev)
+    S = lib.nvae_reduce_splits(rows, Cc)
+    counters = torch.zeros(256, dtype=torch.int32, device=dev)
+
+    def run(fused):
+        rm, rv = torch.zeros(Cc, device=dev), torch.ones(Cc, device=dev)
+        coef = torch.empty(4, Cc, device=dev)
+        sc, sh, mean, istd = (ptr(coef) + i * Cc * 4 for i in range(4))
+        part = torch.empty(S, 2, Cc, device=dev)
+        dg, db, k = torch.zeros(Cc, device=dev), torch.zeros(Cc, device=dev), torch.empty(2, Cc, device=dev)
+        if fused:
+            call("nvae_bn_stats_fin", 1, ptr(x), rows, Cc, ptr(part), ptr(counters), ptr(gamma), ptr(beta), ptr(rm),
+                 ptr(rv), 0.05, 1e-5, sc, sh, mean, istd)
+            call("nvae_bn_bwd_reduce_fin", 1, ptr(x), ptr(dy), rows, Cc, sc, sh, mean, istd, 1, ptr(part),
+                 ptr(counters), ptr(dg), ptr(db), ptr(k), 0)
+        else:
+            call("nvae_bn_stats", 1, ptr(x), rows, Cc, ptr(part))
+            call("nvae_bn_finalize", ptr(part), rows, Cc, ptr(gamma), ptr(beta), ptr(rm), ptr(rv), 0.05, 1e-5, sc,
+                 sh, mean, istd)
+            call("nvae_bn_bwd_reduce", 1, ptr(x), ptr(dy), rows, Cc, sc, sh, 1, ptr(part))
+            call("nvae_bn_bwd_finalize", ptr(part), rows, Cc, sc, mean, istd, ptr(dg), ptr(db), ptr(k), 0)
+        torch.cuda.synchronize()
+        return [t.clone() for t in (coef, rm, rv, dg, db, k)]
+
+    ref = run(False)
+    for _ in range(3):
+        got = run(True)
+        assert int(counters.abs().sum()) == 0
+        for a, b in zip(got, ref):
+            assert rel_err(a, b) < 1e-5
+
+
 @pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
 @pytest.mark.parametrize("shape,ss,bs", [((3, 8, 8, 128), 0.1, 1.0), ((4, 4, 4, 256), 1.0, 0.1), ((2, 32, 32, 32), 1.0, 0.1)])
 def test_se_residual(lib, dev, dtype, shape, ss, bs):
