@@ -53,20 +53,26 @@ class NVAE:
 
         ps = ParamStore(seed)
         self.ps = ps
+        marks = [0]             # flat-buffer offsets where preprocess / encoder / decoder / postprocess end
         self.preprocess = Preprocess(ps, n_encoder_channels, n_preprocess_blocks, n_preprocess_cells,
                                      scale_factor, input_shape)
         mult = self.preprocess.mult
+        marks.append(ps._p_cursor)
         self.encoder = Encoder(ps, n_encoder_channels, n_decoder_channels, n_latent_per_group,
                                res_cells_per_group, n_latent_scales, self.n_groups_per_scale, mult,
                                scale_factor, self.preprocess.output_shape_)
         mult = self.encoder.mult
+        marks.append(ps._p_cursor)
         self.decoder = Decoder(ps, n_encoder_channels, n_decoder_channels, n_latent_per_group,
                                res_cells_per_group, n_latent_scales,
                                list(reversed(self.n_groups_per_scale)), mult, scale_factor,
                                self.encoder.output_shape_)
         mult = self.decoder.mult
+        marks.append(ps._p_cursor)
         self.postprocess = Postprocess(ps, n_postprocess_blocks, n_post_process_cells, mult,
                                        n_decoder_channels, scale_factor, out_channels=input_shape[3])
+        marks.append(ps._p_cursor)
+        self.param_marks = marks
         self.n_groups = self.decoder.n_groups
         # per-image activation footprint decides the scratch pool; generous fixed size
         ps.finalize(self.device, dtype, zero_pool_floats=1 << 24)
@@ -75,6 +81,10 @@ class NVAE:
         self.steps = 0          # updated for each training step (models.py:86-87)
         self.opt_iterations = 0
         self.reducer = None     # parallel.GradReducer when data-parallel
+        # DP: backward runs in three tape segments (postprocess | decoder | encoder + preprocess); the
+        # parameters of a finished segment are all-reduced while the next one computes
+        self.overlap_allreduce = True
+        self._tape_marks = (0, 0)
         dev = self.device
         self.hyper = torch.zeros(L.HY_SIZE, dtype=torch.float32, device=dev)
         self.results = torch.zeros(L.RES_SIZE, dtype=torch.float32, device=dev)
@@ -134,12 +144,14 @@ class NVAE:
         eps = self._draw_eps(ctx, B, eps_list)
         h = self.preprocess(ctx, x)
         enc_dec_combiners, final_x = self.encoder(ctx, h)
+        enc_mark = len(ctx.tape)
         enc_dec_combiners.reverse()    # bottom-up -> top-down, models.py:93
         if nll:
             buf["log_p"].zero_(); buf["log_q"].zero_()
         s = self.decoder(ctx, final_x, enc_dec_combiners, eps, buf["kl_all"], self.coeff, self.hyper,
                          1.0 / B, nll=nll, log_p=buf["log_p"], log_q=buf["log_q"],
                          mu_sigma_list=mu_sigma_list)
+        self._tape_marks = (enc_mark, len(ctx.tape))
         return self.postprocess(ctx, s)
 
     def __call__(self, inputs, nll=False, eps_list=None, training=False):
@@ -240,20 +252,53 @@ class NVAE:
         if nb:
             L.call("nvae_bn_absmax_fwd", L.ptr(ps.params), L.ptr(ps.bn_table), nb, float(self.sr_lambda),
                    L.ptr(self._bn_loss), L.ptr(ps.bn_argmax))
-            ctx.tape.append(lambda: L.call("nvae_bn_absmax_bwd", L.ptr(ps.params), L.ptr(ps.grads),
-                                           L.ptr(ps.bn_table), L.ptr(ps.bn_argmax), nb, float(self.sr_lambda)))
         logits = self._forward(ctx, x, eps_list)
         ops.bernoulli_nll(ctx, logits, x, buf["recon"], 1.0 / B)
         L.call("nvae_kl_absmean", L.ptr(buf["kl_all"]), self.n_groups, B, L.ptr(self.am))
         self._logits = logits
         return ctx
 
-    def _seg_backward(self, ctx: Ctx, B: int):
-        buf = self._buffers(B)
-        L.call("nvae_loss_finalize", L.ptr(buf["kl_all"]), L.ptr(self.am), L.ptr(self.alphas), self.n_groups,
-               B, L.ptr(buf["recon"]), L.ptr(self._bn_loss), L.ptr(self.hyper), L.ptr(self.coeff),
-               L.ptr(buf["kl_loss"]), L.ptr(self.results))
-        ctx.backward()
+    def _seg_backward(self, ctx: Ctx, B: int, part: Optional[int] = None):
+        """Loss + backward.  part=None: everything.  part 0 / 1 / 2: the postprocess / decoder /
+        encoder + preprocess segment of the tape (run in that order); after part k the gradients of
+        flat-buffer range `self.grad_range(k)` are final."""
+        ps = self.ps
+        if part in (None, 0):
+            buf = self._buffers(B)
+            L.call("nvae_loss_finalize", L.ptr(buf["kl_all"]), L.ptr(self.am), L.ptr(self.alphas), self.n_groups,
+                   B, L.ptr(buf["recon"]), L.ptr(self._bn_loss), L.ptr(self.hyper), L.ptr(self.coeff),
+                   L.ptr(buf["kl_loss"]), L.ptr(self.results))
+            nb = len(ps.bn_loss_layers)
+            if nb:      # subgradient of the BN regulariser: depends on the parameters only, so it goes first
+                L.call("nvae_bn_absmax_bwd", L.ptr(ps.params), L.ptr(ps.grads), L.ptr(ps.bn_table),
+                       L.ptr(ps.bn_argmax), nb, float(self.sr_lambda))
+        enc_mark, dec_mark = self._tape_marks
+        if part is None:
+            ctx.backward()
+        elif part == 0:
+            ctx.backward(dec_mark, None)
+        elif part == 1:
+            ctx.backward(enc_mark, dec_mark)
+        else:
+            ctx.backward(0, enc_mark)
+
+    def grad_range(self, part: int):
+        """Flat gradient range completed by backward segment `part` (0: postprocess, 1: decoder,
+        2: preprocess + encoder; the encoder range also holds the combiner convs the decoder runs)."""
+        m = self.param_marks
+        return [(m[3], m[4]), (m[2], m[3]), (m[0], m[2])][part]
+
+    def sync_replicas(self):
+        """Re-align the replicas on rank 0's parameters and state.  The averaged gradients are
+        identical on every rank, but spectral normalisation rewrites W <- W / sigma in place with sigma
+        from f32 atomics, whose summation order differs per GPU: replicas drift by ~1 ulp per step.
+        train.py calls this at every epoch start (a 250 MB broadcast, ~1 ms over xGMI)."""
+        if self.reducer is not None:
+            self.reducer.broadcast_(self.ps.params)
+            self.reducer.broadcast_(self.ps.state)
+
+    def _dp_segments(self) -> bool:
+        return self.reducer is not None and self.overlap_allreduce
 
     def _seg_update(self):
         ps = self.ps
@@ -270,9 +315,16 @@ class NVAE:
         ctx = self._seg_forward(x, eps_list, spectral_norm)
         if self.reducer is not None:
             self.reducer.allreduce_mean_(self.am)
-        self._seg_backward(ctx, B)
-        if self.reducer is not None:
-            self.reducer.allreduce_grads_(self.ps.grads)
+        if self._dp_segments():
+            works = []
+            for part in range(3):
+                self._seg_backward(ctx, B, part)
+                self.reducer.start_allreduce_(self.ps.grads, *self.grad_range(part), works)
+            self.reducer.finish_allreduce_(works)
+        else:
+            self._seg_backward(ctx, B)
+            if self.reducer is not None:
+                self.reducer.allreduce_grads_(self.ps.grads)
         if update:
             self._seg_update()
             self.opt_iterations += 1
@@ -290,6 +342,8 @@ class NVAE:
         """Capture the training step into hipGraphs for a fixed batch shape.  The step is
         [graph: SN + forward + loss stats] -> (all-reduce of the [G] KL statistic when DP)
         -> [graph: loss + backward] -> (gradient all-reduce when DP) -> [graph: Adamax].
+        With a reducer and overlap_allreduce the backward graph is three graphs (postprocess | decoder
+        | encoder + preprocess) and each segment's gradient range is all-reduced while the next replays.
         Host-side scalars (lr, beta) reach the kernels through the `hyper` device buffer, noise is
         drawn in-graph from a device counter, so replays are exact continuations of training."""
         B = int(batch_shape[0])
@@ -305,13 +359,21 @@ class NVAE:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize(self.device)
         pool = torch.cuda.graph_pool_handle()
-        g1, g2, g3 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        g1, g3 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         # thread_local: a NCCL/RCCL watchdog thread may touch the HIP API while we capture
         kw = dict(pool=pool, capture_error_mode="thread_local")
         with torch.cuda.graph(g1, **kw):
             ctx = self._seg_forward(self._static_x, None)
-        with torch.cuda.graph(g2, **kw):
-            self._seg_backward(ctx, B)
+        if self._dp_segments():
+            g2 = []
+            for part in range(3):
+                g2.append(torch.cuda.CUDAGraph())
+                with torch.cuda.graph(g2[-1], **kw):
+                    self._seg_backward(ctx, B, part)
+        else:
+            g2 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g2, **kw):
+                self._seg_backward(ctx, B)
         with torch.cuda.graph(g3, **kw):
             self._seg_update()
         self._plan = (g1, g2, g3, B)
@@ -326,9 +388,16 @@ class NVAE:
         g1.replay()
         if self.reducer is not None:
             self.reducer.allreduce_mean_(self.am)
-        g2.replay()
-        if self.reducer is not None:
-            self.reducer.allreduce_grads_(self.ps.grads)
+        if isinstance(g2, list):
+            works = []
+            for part, g in enumerate(g2):
+                g.replay()
+                self.reducer.start_allreduce_(self.ps.grads, *self.grad_range(part), works)
+            self.reducer.finish_allreduce_(works)
+        else:
+            g2.replay()
+            if self.reducer is not None:
+                self.reducer.allreduce_grads_(self.ps.grads)
         g3.replay()
         self.opt_iterations += 1
         self.steps += 1

@@ -110,14 +110,19 @@ class Ctx:
                 fn()
         self.deferred.clear()
 
-    def backward(self):
-        for fn in reversed(self.tape):
+    def backward(self, lo: int = 0, hi: Optional[int] = None):
+        """Run the tape entries [lo, hi) in reverse and join the side stream, so that every gradient
+        those entries produce is complete on the current stream.  backward() runs the whole tape;
+        data-parallel steps run it in segments and all-reduce each segment's parameters meanwhile."""
+        hi = len(self.tape) if hi is None else hi
+        for fn in reversed(self.tape[lo:hi]):
             fn()
         if self.side is not None:
             self.flush_side()
             torch.cuda.current_stream().wait_stream(self.side)   # join before the optimizer / all-reduce
-        self.keep.clear()
-        self.tape.clear()
+        del self.tape[lo:hi]
+        if not self.tape:
+            self.keep.clear()
 
 
 # ------------------------------------------------------------------------------------------

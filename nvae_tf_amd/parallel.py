@@ -47,6 +47,31 @@ class GradReducer:
             t.div_(self.world)
         return t
 
+    def start_allreduce_(self, flat: torch.Tensor, lo: int, hi: int, works: list) -> None:
+        """Launch (without waiting) the bucketed mean all-reduce of flat[lo:hi].  With RCCL the
+        collectives run on the communicator's own stream, ordered after everything already issued on
+        the current stream, so kernels launched afterwards (the rest of backward) overlap with them.
+        Finish with `finish_allreduce_`."""
+        if (self.world == 1 and not self.force) or hi <= lo:
+            return
+        seg = flat[lo:hi]
+        for s in self.buckets(seg.numel()):
+            w, nd = self._allreduce_mean(seg[s], True)
+            works.append((w, seg[s] if nd else None))
+
+    def finish_allreduce_(self, works: list) -> None:
+        """Make the current stream wait for the collectives started by `start_allreduce_`."""
+        for w, div in works:
+            w.wait()
+            if div is not None:
+                div.div_(self.world)
+        works.clear()
+
+    def broadcast_(self, t: torch.Tensor, src: int = 0) -> torch.Tensor:
+        if self.world > 1 or self.force:
+            dist.broadcast(t, src, group=self.group)
+        return t
+
     def allreduce_grads_(self, flat: torch.Tensor) -> torch.Tensor:
         """Average the flat gradient buffer across ranks, bucket by bucket (all in flight at once)."""
         if self.world == 1 and not self.force:

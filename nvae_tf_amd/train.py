@@ -45,6 +45,7 @@ def train(args, model, train_data, test_data, rank=0, world=1):
     captured = False
     for epoch in range(args.resume_from, args.epochs):
         model.on_epoch_begin(epoch)
+        model.sync_replicas()       # data-parallel: bound the ulp drift of the replicas (models.sync_replicas)
         t0, seen, losses = time.time(), 0, []
         for i, (images, _) in enumerate(train_data):
             images = images[rank::world] if world > 1 else images       # shard the batch over ranks

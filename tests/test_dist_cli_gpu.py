@@ -47,6 +47,78 @@ def test_rccl_single_rank_graph_step(lib, dev):
         dist.destroy_process_group()
 
 
+def _dp_worker(rank, world, port, q):
+    """One of two data-parallel ranks sharing the box's single GPU (gloo carries the collectives; the
+    RCCL path needs one GPU per rank and is covered single-rank above and by the driver's N>1 runs)."""
+    import torch.distributed as dist
+    from nvae_tf_amd.parallel import GradReducer
+    from oracle.nvae_oracle import synthetic_batch
+    try:
+        dev = torch.device("cuda", 0)
+        torch.cuda.set_device(dev)
+        dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+        x = synthetic_batch(8, seed=10 + rank).float()
+        ref, dp = _model(dev), _model(dev)           # same seed -> identical replicas on every rank
+        for m in (ref, dp):
+            m.steps = 50
+        # reference: plain backward, collectives issued by hand on whole buffers
+        ref._set_hyper()
+        ctx = ref._seg_forward(ref._as_input(x), None)
+        dist.all_reduce(ref.am); ref.am.div_(world)
+        ref._seg_backward(ctx, 8)
+        torch.cuda.synchronize()
+        g = ref.ps.grads.clone()
+        dist.all_reduce(g); g.div_(world)
+        # product path: segmented backward, bucketed async all-reduce per segment
+        dp.reducer = GradReducer(bucket_bytes=1 << 18)
+        assert dp._dp_segments()
+        # (both replicas draw their noise from Philox counter 0 with the same seed)
+        dp.train_step(x, update=False)
+        torch.cuda.synchronize()
+        err_eager = float((dp.ps.grads - g).abs().max() / g.abs().max())
+        m = dp.param_marks
+        assert m[0] == 0 and m[4] == dp.ps._p_cursor and m[1] < m[2] < m[3] < m[4]
+        # graphed path: parameters stay identical across ranks after optimizer steps
+        dp.capture_train_step(x.shape, warmup=1)
+        dist.broadcast(dp.ps.params, 0); dist.broadcast(dp.ps.state, 0)
+        dp.ps.adam_m.zero_(); dp.ps.adam_u.zero_()
+        for _ in range(2):
+            out = dp.train_step_graphed(x)
+        torch.cuda.synchronize()
+        mine = dp.ps.params.clone()
+        other = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(other, mine)
+        drift = float((other[0] - other[1]).abs().max())
+        dp.sync_replicas()
+        dist.all_gather(other, dp.ps.params.clone())
+        assert float((other[0] - other[1]).abs().max()) == 0.0
+        # local gradients differ between ranks (different data), so matching parameters prove the exchange
+        q.put((rank, err_eager, drift, float(out["loss"])))
+        dist.destroy_process_group()
+    except Exception as e:      # surface the failure in the parent instead of hanging it
+        import traceback
+        q.put((rank, "error", traceback.format_exc(), str(e)))
+
+
+def test_dp_two_ranks_one_gpu_gloo(lib, dev):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29900 + os.getpid() % 90
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=420) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for r in res:
+        assert r[1] != "error", r[2]
+        _, err_eager, drift, loss = r
+        assert err_eager < 2e-5, r          # same sums, different f32 association (buckets / atomics)
+        assert drift < 1e-6, r              # ulps from spectral norm's atomics; sync_replicas() zeroes it
+        assert loss == loss
+
+
 def test_train_cli_modes(lib, dev, tmp_path, capsys):
     from nvae_tf_amd import train
     common = ["--synthetic", "--batch_size", "16", "--n_encoder_channels", "16", "--n_decoder_channels", "16",
