@@ -200,6 +200,22 @@ int nvae_bernoulli_fwd(int dtype, const float* logits, const void* x, float* rec
 int nvae_bernoulli_bwd(int dtype, const float* logits, const void* x, void* dlogits, long n,
                        float inv_batch, void* stream);
 
+/* ---- discretised mixture of logistics head (csrc/dmol.hip) ------------------------------------
+ * NOT in the reference (train.py:219, README.md:25-27 list the CIFAR / CelebA heads as to-do); the
+ * specification is oracle/nvae_oracle.py::dmol_log_prob / dmol_sample (NVAE paper, PixelCNN++).
+ * logits: f32 [B*HW, ld], ld >= 10*M, channel layout [M mixture logits | per colour: M means,
+ * M log-scales (clamped at -7), M coefficient logits (tanh)].  x: f32 [B*HW, 3] in [0, 1].
+ *   nll[b]  = -sum_pixels log p(x)                                    (one workgroup per image)
+ *   dlogits = scale * d nll / d logits, in `dtype`, channels [10M, ld) written as zero
+ *   sample: one draw per pixel from uniform noise u_mix [B*HW, M], u_pix [B*HW, 3] in (0, 1);
+ *           temperature divides the mixture logits and multiplies the logistic scale.           */
+int nvae_dmol_fwd(const float* logits, int ld, const float* x, float* nll, int B, int HW, int M,
+                  void* stream);
+int nvae_dmol_bwd(int dtype, const float* logits, int ld, const float* x, void* dlogits, int B, int HW,
+                  int M, float scale, void* stream);
+int nvae_dmol_sample(const float* logits, int ld, const float* u_mix, const float* u_pix, float* out,
+                     int B, int HW, int M, float temperature, void* stream);
+
 /* ---- KL balancing + loss assembly, models.py:121-126, 204-222 ------------------------------ */
 #define NVAE_HY_LR 0       /* lr / (1 - beta1^t)                       */
 #define NVAE_HY_BETA 1     /* KL warm-up coefficient (models.py:122)   */

@@ -74,6 +74,9 @@ _SIGS = {
     "nvae_sampler_bwd": [_i, _p, _p, _p, _p, _p, _p, _f, _p, _p, _i, _i, _i],
     "nvae_bernoulli_fwd": [_i, _p, _p, _p, _i, _i, _i, _i, _i],
     "nvae_bernoulli_bwd": [_i, _p, _p, _p, _l, _f],
+    "nvae_dmol_fwd": [_p, _i, _p, _p, _i, _i, _i],
+    "nvae_dmol_bwd": [_i, _p, _i, _p, _p, _i, _i, _i, _f],
+    "nvae_dmol_sample": [_p, _i, _p, _p, _p, _i, _i, _i, _f],
     "nvae_kl_absmean": [_p, _i, _i, _p],
     "nvae_loss_finalize": [_p, _p, _p, _i, _i, _p, _p, _p, _p, _p, _p],
     "nvae_bn_absmax_fwd": [_p, _p, _i, _f, _p, _p],

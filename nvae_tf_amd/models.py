@@ -30,8 +30,12 @@ class NVAE:
                  n_preprocess_cells, n_latent_per_group, n_latent_scales, n_groups_per_scale,
                  n_postprocess_blocks, n_post_process_cells, sr_lambda, scale_factor, total_epochs,
                  n_total_iterations, step_based_warmup, input_shape, *, device="cuda:0",
-                 dtype=torch.bfloat16, seed=1, lr_decay_steps: Optional[int] = None, base_lr=1e-3):
-        """Positional arguments as models.py:17-36.  input_shape = [B, H, W, C] (B ignored)."""
+                 dtype=torch.bfloat16, seed=1, lr_decay_steps: Optional[int] = None, base_lr=1e-3,
+                 head: Optional[str] = None, num_mixture_dec: int = 10):
+        """Positional arguments as models.py:17-36.  input_shape = [B, H, W, C] (B ignored).
+        head: "bernoulli" (the reference's binary-MNIST likelihood, default for C == 1) or "dmol"
+        (discretised mixture of `num_mixture_dec` logistics over RGB, default for C == 3; the
+        reference leaves it unimplemented)."""
         assert len(n_groups_per_scale) == n_latent_scales
         self.sr_lambda = sr_lambda
         self.n_latent_per_group = n_latent_per_group
@@ -69,8 +73,13 @@ class NVAE:
                                self.encoder.output_shape_)
         mult = self.decoder.mult
         marks.append(ps._p_cursor)
+        self.head = head or ("bernoulli" if input_shape[3] == 1 else "dmol")
+        assert self.head in ("bernoulli", "dmol")
+        assert self.head == "bernoulli" or input_shape[3] == 3, "the mixture-of-logistics head models RGB"
+        self.num_mixture_dec = int(num_mixture_dec)
+        out_channels = input_shape[3] if self.head == "bernoulli" else 10 * self.num_mixture_dec
         self.postprocess = Postprocess(ps, n_postprocess_blocks, n_post_process_cells, mult,
-                                       n_decoder_channels, scale_factor, out_channels=input_shape[3])
+                                       n_decoder_channels, scale_factor, out_channels=out_channels)
         marks.append(ps._p_cursor)
         self.param_marks = marks
         self.n_groups = self.decoder.n_groups
@@ -128,8 +137,11 @@ class NVAE:
         if isinstance(data, (tuple, list)):
             data = data[0]   # labelled data: drop the label (models.py:113-115)
         x = data.to(self.device)
-        if x.dtype != self.dtype:
-            x = x.to(self.dtype)
+        # the mixture-of-logistics likelihood needs the exact 8-bit levels: keep the image in f32 and
+        # cast a copy for the network inside _forward
+        want = torch.float32 if self.head == "dmol" else self.dtype
+        if x.dtype != want:
+            x = x.to(want)
         return x.contiguous()
 
     def _draw_eps(self, ctx: Ctx, B: int, eps_list):
@@ -142,6 +154,10 @@ class NVAE:
         B = x.shape[0]
         buf = self._buffers(B)
         eps = self._draw_eps(ctx, B, eps_list)
+        if x.dtype != self.dtype:
+            xin = ctx.empty(x.shape)
+            L.call("nvae_cast", L.F32, ctx.dt, L.ptr(x), L.ptr(xin), x.numel())
+            x = xin
         h = self.preprocess(ctx, x)
         enc_dec_combiners, final_x = self.encoder(ctx, h)
         enc_mark = len(ctx.tape)
@@ -165,6 +181,8 @@ class NVAE:
         logits = self._forward(ctx, x, eps_list, nll=nll, mu_sigma_list=ms)
         buf = self._buffers(B)
         z_params = [DistributionParams(m[0], m[1], m[2], m[3]) for m in ms]
+        if self.head == "dmol":     # hide the head conv's padding channels
+            logits = Var(logits.t[..., :10 * self.num_mixture_dec], False)
         if nll:
             return logits.t, z_params, buf["log_p"].clone(), buf["log_q"].clone()
         zeros = torch.zeros(B, dtype=torch.float32, device=self.device)
@@ -200,8 +218,12 @@ class NVAE:
         B = x.shape[0]
         out = torch.empty(B, dtype=torch.float32, device=self.device)
         ctx = Ctx(self.ps, self.dtype, training=False, record=False)
-        ops.bernoulli_nll(ctx, Var(reconstruction.to(torch.float32).contiguous(), False), x, out, 1.0 / B,
-                          crop=crop_output)
+        logits = Var(reconstruction.to(torch.float32).contiguous(), False)
+        if self.head == "dmol":
+            assert not crop_output, "crop_output is the MNIST 28x28 crop (models.py:243-245)"
+            ops.dmol_nll(ctx, logits, x, out, 1.0 / B, self.num_mixture_dec)
+        else:
+            ops.bernoulli_nll(ctx, logits, x, out, 1.0 / B, crop=crop_output)
         return out
 
     def calculate_bn_loss(self) -> torch.Tensor:
@@ -253,7 +275,10 @@ class NVAE:
             L.call("nvae_bn_absmax_fwd", L.ptr(ps.params), L.ptr(ps.bn_table), nb, float(self.sr_lambda),
                    L.ptr(self._bn_loss), L.ptr(ps.bn_argmax))
         logits = self._forward(ctx, x, eps_list)
-        ops.bernoulli_nll(ctx, logits, x, buf["recon"], 1.0 / B)
+        if self.head == "dmol":
+            ops.dmol_nll(ctx, logits, x, buf["recon"], 1.0 / B, self.num_mixture_dec)
+        else:
+            ops.bernoulli_nll(ctx, logits, x, buf["recon"], 1.0 / B)
         L.call("nvae_kl_absmean", L.ptr(buf["kl_all"]), self.n_groups, B, L.ptr(self.am))
         self._logits = logits
         return ctx
@@ -347,7 +372,8 @@ class NVAE:
         Host-side scalars (lr, beta) reach the kernels through the `hyper` device buffer, noise is
         drawn in-graph from a device counter, so replays are exact continuations of training."""
         B = int(batch_shape[0])
-        self._static_x = torch.zeros(tuple(batch_shape), dtype=self.dtype, device=self.device)
+        self._static_x = torch.zeros(tuple(batch_shape), device=self.device,
+                                     dtype=torch.float32 if self.head == "dmol" else self.dtype)
         self._set_hyper()
         side = torch.cuda.Stream(device=self.device)
         side.wait_stream(torch.cuda.current_stream())
@@ -404,9 +430,16 @@ class NVAE:
         return self._step_outputs(B)
 
     # ------------------------------------------------------------------ sampling (models.py:137-189)
-    def sample(self, n_samples=16, temperature=1.0, greyscale=True, eps_list=None):
+    def _images(self, logits: torch.Tensor, greyscale: bool, dmol_noise=None) -> torch.Tensor:
+        if self.head == "dmol":      # one draw from the mixture per pixel (t = 1, as NVAE does for its output)
+            u_mix, u_pix = dmol_noise if dmol_noise is not None else (None, None)
+            return ops.dmol_sample(logits, self.num_mixture_dec, 1.0, u_mix, u_pix)
+        return torch.sigmoid(logits) if greyscale else torch.bernoulli(torch.sigmoid(logits))
+
+    def sample(self, n_samples=16, temperature=1.0, greyscale=True, eps_list=None, dmol_noise=None):
         """Ancestral sampling.  Temperature scales z0's sigma only (Q8).  Returns
-        (images [B,H,W,C] f32 in [0,1], last_s, z1, z2) like the reference."""
+        (images [B,H,W,C] f32 in [0,1], last_s, z1, z2) like the reference.  dmol_noise: optional
+        (u_mix [B,H,W,M], u_pix [B,H,W,3]) uniforms for the mixture-of-logistics head."""
         ps = self.ps
         B = n_samples
         ps.begin_step()
@@ -442,7 +475,7 @@ class NVAE:
             else:
                 s = layer(ctx, s)
         logits = self.postprocess(ctx, s).t
-        images = torch.sigmoid(logits) if greyscale else torch.bernoulli(torch.sigmoid(logits))
+        images = self._images(logits, greyscale, dmol_noise)
         # z1, z2: two more draws from the last group's prior (models.py:175-176)
         zs = []
         for _ in range(2):
@@ -461,4 +494,4 @@ class NVAE:
         out = last(ctx, Var(s.to(self.device, self.dtype).contiguous(), False),
                    Var(z.to(self.device, self.dtype).contiguous(), False))
         logits = self.postprocess(ctx, out).t
-        return torch.sigmoid(logits)
+        return self._images(logits, True)

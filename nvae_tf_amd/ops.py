@@ -418,6 +418,34 @@ def bernoulli_nll(ctx: Ctx, logits: Var, x: torch.Tensor, recon_out: torch.Tenso
         ctx.tape.append(bwd)
 
 
+def dmol_nll(ctx: Ctx, logits: Var, x32: torch.Tensor, recon_out: torch.Tensor, inv_batch: float, n_mix: int):
+    """-log p(x) under the discretised mixture of logistics (oracle dmol_log_prob); x32 f32 in [0, 1]."""
+    B, H, W, ld = logits.t.shape
+    assert logits.t.dtype == torch.float32 and x32.dtype == torch.float32 and x32.shape == (B, H, W, 3)
+    call("nvae_dmol_fwd", ptr(logits.t), ld, ptr(x32), ptr(recon_out), B, H * W, n_mix)
+    if ctx.record:
+        def bwd():
+            logits.g = ctx.empty(logits.t.shape)
+            call("nvae_dmol_bwd", ctx.dt, ptr(logits.t), ld, ptr(x32), ptr(logits.g), B, H * W, n_mix, inv_batch)
+        ctx.tape.append(bwd)
+
+
+def dmol_sample(logits: torch.Tensor, n_mix: int, temperature: float = 1.0, u_mix=None, u_pix=None,
+                generator=None) -> torch.Tensor:
+    """One RGB draw in [0, 1] per pixel (oracle dmol_sample).  Noise defaults to torch's device RNG."""
+    B, H, W, ld = logits.shape
+    dev = logits.device
+    if u_mix is None:
+        u_mix = torch.empty(B, H, W, n_mix, device=dev).uniform_(1e-5, 1 - 1e-5, generator=generator)
+    if u_pix is None:
+        u_pix = torch.empty(B, H, W, 3, device=dev).uniform_(1e-5, 1 - 1e-5, generator=generator)
+    u_mix = u_mix.to(dev, torch.float32).contiguous()
+    u_pix = u_pix.to(dev, torch.float32).contiguous()
+    out = torch.empty(B, H, W, 3, dtype=torch.float32, device=dev)
+    call("nvae_dmol_sample", ptr(logits), ld, ptr(u_mix), ptr(u_pix), ptr(out), B, H * W, n_mix, float(temperature))
+    return out
+
+
 def randn(ctx: Ctx, shape, seed: int, counter: torch.Tensor) -> torch.Tensor:
     out = ctx.empty(shape, torch.float32)
     call("nvae_randn", ptr(out), out.numel(), seed, ptr(counter))

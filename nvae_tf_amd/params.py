@@ -24,6 +24,7 @@ ALIGN = 8   # floats
 class Slot:
     off: int
     shape: Tuple[int, ...]
+    logical: Optional[int] = None     # visible size of the last axis when the storage is padded
 
     @property
     def numel(self) -> int:
@@ -70,7 +71,7 @@ class ParamStore:
         self.params = self.grads = self.state = None
 
     # ---- declaration -----------------------------------------------------------------------
-    def _alloc(self, name, shape, init: torch.Tensor, state=False) -> Slot:
+    def _alloc(self, name, shape, init: torch.Tensor, state=False, logical: Optional[int] = None) -> Slot:
         n = int(np.prod(shape))
         if state:
             s = Slot(self._s_cursor, tuple(shape))
@@ -80,7 +81,8 @@ class ParamStore:
             s = Slot(self._p_cursor, tuple(shape))
             self._p_cursor += (n + ALIGN - 1) // ALIGN * ALIGN
             self.slots[name] = s
-            self.n_trainable += n
+            self.n_trainable += n if logical is None else n // shape[-1] * logical
+        s.logical = logical if (logical is not None and logical != shape[-1]) else None
         self._init.append((s, init.reshape(-1).to(torch.float32), state))
         return s
 
@@ -88,14 +90,28 @@ class ParamStore:
         lim = math.sqrt(6.0 / (fan_in + fan_out))
         return (torch.rand(shape, generator=self.gen, dtype=torch.float64) * 2 - 1) * lim
 
-    def conv(self, name, k, cin, cout, bias=True, sn=True) -> ConvParam:
-        w = self._alloc(name + ".w", (k, k, cin, cout), self._glorot((k, k, cin, cout), k * k * cin, k * k * cout))
-        b = self._alloc(name + ".b", (cout,), torch.zeros(cout)) if bias else None
+    def conv(self, name, k, cin, cout, bias=True, sn=True, pad_cout: int = 1) -> ConvParam:
+        """pad_cout > 1: the kernels see ceil(cout / pad_cout) * pad_cout output channels (the MFMA
+        gradient kernels want a multiple of 8); the extra channels have zero weights, get zero
+        gradients and stay zero, and are hidden from get()/load_named()/n_trainable."""
+        cp = (cout + pad_cout - 1) // pad_cout * pad_cout
+
+        def padded(t):
+            if cp == cout:
+                return t
+            out = torch.zeros(t.shape[:-1] + (cp,), dtype=t.dtype)
+            out[..., :cout] = t
+            return out
+
+        w = self._alloc(name + ".w", (k, k, cin, cp),
+                        padded(self._glorot((k, k, cin, cout), k * k * cin, k * k * cout)), logical=cout)
+        b = self._alloc(name + ".b", (cp,), torch.zeros(cp), logical=cout) if bias else None
         u = None
         if sn:
             ui = torch.randn(cout, generator=self.gen, dtype=torch.float64).clamp(-2, 2) * 0.02
-            u = self._alloc(name + ".u", (cout,), ui, state=True)
-        c = ConvParam(name, k, cin, cout, w, b, u)
+            u = self._alloc(name + ".u", (cp,), padded(ui), state=True, logical=cout)
+        c = ConvParam(name, k, cin, cp, w, b, u)
+        c.cout_logical = cout
         self.convs.append(c)
         return c
 
@@ -189,17 +205,22 @@ class ParamStore:
     def sview(self, slot: Slot) -> torch.Tensor:
         return self.state[slot.off:slot.off + slot.numel]
 
+    @staticmethod
+    def _logical(t: torch.Tensor, s: Slot) -> torch.Tensor:
+        t = t.reshape(s.shape)
+        return t if s.logical is None else t[..., :s.logical]
+
     def get(self, name: str) -> torch.Tensor:
         s = self.slots[name]
-        return self.view(s).reshape(s.shape)
+        return self._logical(self.view(s), s)
 
     def get_grad(self, name: str) -> torch.Tensor:
         s = self.slots[name]
-        return self.gview(s).reshape(s.shape)
+        return self._logical(self.gview(s), s)
 
     def get_state(self, name: str) -> torch.Tensor:
         s = self.sslots[name]
-        return self.sview(s).reshape(s.shape)
+        return self._logical(self.sview(s), s)
 
     def load_named(self, params: Dict[str, torch.Tensor], state: Dict[str, torch.Tensor]):
         """Copy weights/state in by name (used by the parity tests and checkpoint loading)."""

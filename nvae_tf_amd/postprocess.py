@@ -75,7 +75,10 @@ class Postprocess:
                 up = cell_idx == 0
                 self.cells.append(PostprocessCell(ps, f"post.cell{idx}", c_in if up else c, c, 1, scale_factor, up))
                 idx += 1
-        self.final_conv = ps.conv("post.final.conv", 3, n_channels_decoder * mult, out_channels)
+        # a mixture-of-logistics head has 10*M (= 100) output channels: padded to a multiple of 8 so
+        # that its data/weight gradients run on the MFMA kernels (params.ParamStore.conv)
+        self.final_conv = ps.conv("post.final.conv", 3, n_channels_decoder * mult, out_channels,
+                                  pad_cout=8 if out_channels > 8 else 1)
         self.mult = mult
 
     def __call__(self, ctx: Ctx, x: Var) -> Var:

@@ -51,6 +51,17 @@ class OracleConfig:
     step_based_warmup: bool = True
     input_hw: int = 32
     input_channels: int = 1
+    # output head: "bernoulli" (the reference, models.py:242-250) or "dmol" - the discretised mixture of
+    # logistics of the NVAE paper, which the reference leaves unimplemented (train.py:219, README.md:25-27)
+    head: str = "bernoulli"
+    num_mixture_dec: int = 10
+
+    @property
+    def output_channels(self) -> int:
+        if self.head == "bernoulli":
+            return self.input_channels
+        assert self.input_channels == 3, "the mixture-of-logistics head models RGB"
+        return 10 * self.num_mixture_dec
 
     @property
     def n_latent_scales(self) -> int:
@@ -291,7 +302,7 @@ class OracleNVAE:
                 s.se(n + ".se", C)
                 self.post_cells.append((n, cin, C, up))
                 idx += 1
-        s.conv("post.final.conv", 3, D * mult, c.input_channels)
+        s.conv("post.final.conv", 3, D * mult, c.output_channels)
 
     def _build_bnswishconv(self, n, c_in, c_out, stride):
         """preprocess.py:77-101 (+ SkipScaler 42-63)."""
@@ -547,6 +558,8 @@ class OracleNVAE:
         if crop_output:
             inputs = inputs[:, 2:30, 2:30, :]
             logits = logits[:, 2:30, 2:30, :]
+        if self.cfg.head == "dmol":
+            return -dmol_log_prob(inputs, logits, self.cfg.num_mixture_dec).sum(dim=(1, 2))
         return (F.softplus(logits) - inputs * logits).sum(dim=(1, 2, 3))
 
     def calculate_bn_loss(self):
@@ -634,6 +647,8 @@ class OracleNVAE:
             else:
                 s = self.rescaler(f"dec.up{layer[1]}", s, True, False)
         logits = self.postprocess(s, False)
+        if self.cfg.head == "dmol":
+            return logits          # draw pixels with dmol_sample(logits, M, u_mix, u_pix, t)
         return torch.sigmoid(logits) if greyscale else logits
 
     def neg_log_likelihood(self, x, eps_lists):
@@ -641,9 +656,78 @@ class OracleNVAE:
         logs = []
         for eps in eps_lists:
             logits, _, log_p, log_q, _ = self.call(x, eps, training=False, nll=True)
-            logs.append(-self.calculate_recon_loss(x, logits, crop_output=True) - log_q + log_p)
+            crop = self.cfg.head == "bernoulli"      # the 28x28 crop is MNIST's zero padding (Q5)
+            logs.append(-self.calculate_recon_loss(x, logits, crop_output=crop) - log_q + log_p)
         k = len(eps_lists)
         return -(torch.logsumexp(torch.stack(logs), dim=0) - math.log(float(k))).mean()
+
+
+# --------------------------------------------------------------------------------------
+# Discretised mixture of logistics (NOT in the reference: SURVEY 8f "ext"; specified here after the
+# NVAE paper sec. 3 / PixelCNN++: M mixtures, RGB sub-pixel conditioning through tanh coefficients,
+# 8-bit bins of half-width 1/255 on [-1, 1], log-scales clamped at -7).  Channel layout of the
+# 10*M logits per pixel: [0, M) mixture logits; then for colour c in (R, G, B) a block of 3M at
+# M + 3M*c: means [0, M), log-scales [M, 2M), coefficient logits [2M, 3M).
+# --------------------------------------------------------------------------------------
+def dmol_split(logits, M):
+    lp = logits[..., :M]
+    blk = logits[..., M:].reshape(*logits.shape[:-1], 3, 3 * M)
+    means = blk[..., :M]                                  # [..., 3, M]
+    log_scales = torch.clamp(blk[..., M:2 * M], min=-7.0)
+    coeffs = torch.tanh(blk[..., 2 * M:])
+    return lp, means, log_scales, coeffs
+
+
+def dmol_log_prob(x01, logits, M):
+    """log p(x) per pixel, [B, H, W]; x01 in [0, 1] with 3 channels."""
+    x = 2.0 * x01 - 1.0
+    lp, means, log_scales, coeffs = dmol_split(logits, M)
+    xs = x.unsqueeze(-1)                                  # [B, H, W, 3, 1]
+    m1 = means[..., 0, :]
+    m2 = means[..., 1, :] + coeffs[..., 0, :] * xs[..., 0, :]
+    m3 = means[..., 2, :] + coeffs[..., 1, :] * xs[..., 0, :] + coeffs[..., 2, :] * xs[..., 1, :]
+    mu = torch.stack((m1, m2, m3), dim=-2)                # [B, H, W, 3, M]
+    centered = xs - mu
+    inv_stdv = torch.exp(-log_scales)
+    plus_in = inv_stdv * (centered + 1.0 / 255.0)
+    min_in = inv_stdv * (centered - 1.0 / 255.0)
+    cdf_delta = torch.sigmoid(plus_in) - torch.sigmoid(min_in)
+    log_cdf_plus = plus_in - F.softplus(plus_in)
+    log_one_minus_cdf_min = -F.softplus(min_in)
+    mid_in = inv_stdv * centered
+    log_pdf_mid = mid_in - log_scales - 2.0 * F.softplus(mid_in)
+    mid_safe = torch.where(cdf_delta > 1e-5, torch.log(torch.clamp(cdf_delta, min=1e-10)),
+                           log_pdf_mid - math.log(127.5))
+    lpc = torch.where(xs < -0.999, log_cdf_plus, torch.where(xs > 0.99, log_one_minus_cdf_min, mid_safe))
+    return torch.logsumexp(lpc.sum(dim=-2) + F.log_softmax(lp, dim=-1), dim=-1)
+
+
+def dmol_sample(logits, M, u_mix, u_pix, t=1.0):
+    """One draw in [0, 1]^3 per pixel.  u_mix [B,H,W,M], u_pix [B,H,W,3] ~ U(1e-5, 1 - 1e-5).  The
+    temperature sharpens the mixture choice (logits / t) and scales the logistic noise by t."""
+    lp, means, log_scales, coeffs = dmol_split(logits, M)
+    gumbel = -torch.log(-torch.log(u_mix))
+    k = torch.argmax(lp / t + gumbel, dim=-1)             # [B, H, W]
+    idx = k[..., None, None].expand(*k.shape, 3, 1)
+    mu = torch.gather(means, -1, idx).squeeze(-1)         # [B, H, W, 3]
+    ls = torch.gather(log_scales, -1, idx).squeeze(-1)
+    co = torch.gather(coeffs, -1, idx).squeeze(-1)
+    x = mu + torch.exp(ls) * t * (torch.log(u_pix) - torch.log(1.0 - u_pix))
+    x0 = torch.clamp(x[..., 0], -1, 1)
+    x1 = torch.clamp(x[..., 1] + co[..., 0] * x0, -1, 1)
+    x2 = torch.clamp(x[..., 2] + co[..., 1] * x0 + co[..., 2] * x1, -1, 1)
+    return torch.stack((x0, x1, x2), dim=-1) / 2.0 + 0.5
+
+
+def synthetic_rgb_batch(B, hw=32, seed=1, dtype=torch.float64):
+    """8-bit RGB images in [0, 1] (k/255): smooth random blobs plus noise, so that all three cases of
+    the discretised likelihood (x = 0, x = 255, interior bins) occur."""
+    g = torch.Generator().manual_seed(seed)
+    low = torch.rand(B, 3, max(hw // 8, 1), max(hw // 8, 1), generator=g, dtype=torch.float64)
+    img = F.interpolate(low, size=(hw, hw), mode="bilinear", align_corners=False)
+    img = (img - 0.5) * 2.2 + 0.5 + 0.05 * torch.randn(B, 3, hw, hw, generator=g, dtype=torch.float64)
+    img = torch.round(torch.clamp(img, 0, 1) * 255.0) / 255.0
+    return img.permute(0, 2, 3, 1).contiguous().to(dtype)
 
 
 def synthetic_batch(B, seed=1, hw=32, p=0.19, dtype=torch.float64):
