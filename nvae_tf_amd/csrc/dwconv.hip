@@ -1,120 +1,251 @@
-// Depthwise 5x5 convolution (decoder.py:130), NHWC, vectorised over channels.
-// Spatial extents on this path are 4x4 / 8x8 with 768-1536 channels, so a whole image slab is a few
-// hundred KB and the 25-tap re-reads are served by L1/L2: the kernel is bound by one HBM read + one
-// write of the tensor.  Weights are the f32 masters [5,5,C] (25*C*4 B, L2-resident).
+// Depthwise 5x5 convolution (decoder.py:130), NHWC: forward / data gradient (same kernel, flipped taps)
+// and weight gradient.  HBM-bound: one read + one write of the tensor (forward), two reads (wgrad).
+//
+// A workgroup owns a TH x TW tile of output pixels of one image and a strip of 64 channels (128 B of
+// bf16 per pixel = one cache line).  The (TH+4) x (TW+4) input halo is staged once in LDS with 16-B
+// loads (zero outside the image: 'same' padding costs nothing afterwards), then thread (cg, pl) works
+// on 4 channels (one 8-B / 16-B LDS read) for pixel lane pl:
+//   forward: R vertically adjacent outputs per thread, so each halo row read feeds up to R outputs
+//            (10 LDS reads per output instead of 25 for R = 4); the 25 x 4 taps live in registers;
+//   wgrad:   4 horizontally adjacent dy pixels per thread against an 8-wide x row per tap row
+//            (11 LDS reads per pixel), 25 x 4 accumulators in registers across every tile the
+//            workgroup visits, one shuffle + LDS reduction and one atomic per (tap, channel) at the end.
+// Tiles: 8x8 (R = 4) for H, W > 4, 4x4 (R = 1) for the 4x4 tower.  Weights are the f32 masters [5,5,C].
+//
+// Measured on MI355X before this layout (thread = channel pair / pixel, taps re-read from L1/L2): the
+// CIFAR-10 shape B64 x 16x16 x 1536 took 173 us forward and 1 180 us for the weight gradient, i.e.
+// 0.6 / 0.08 TB/s of algorithmic traffic.
 #include "common.h"
+#include "conv_common.h"      // glds16 (LDS-DMA), wait_vmcnt, zero_page
 
-// two adjacent channels in one LDS / global access
-template <typename T> __device__ __forceinline__ void ld2(const T* p, float& a, float& b);
-template <> __device__ __forceinline__ void ld2<bf16>(const bf16* p, float& a, float& b) {
-    const unsigned v = *(const unsigned*)p;
-    a = __uint_as_float(v << 16); b = __uint_as_float(v & 0xffff0000u);
-}
-template <> __device__ __forceinline__ void ld2<float>(const float* p, float& a, float& b) {
-    const float2 v = *(const float2*)p;
-    a = v.x; b = v.y;
-}
-template <typename T> __device__ __forceinline__ void st2(T* p, float a, float b);
-template <> __device__ __forceinline__ void st2<bf16>(bf16* p, float a, float b) {
-    *(unsigned*)p = (unsigned)f2bf(a) | ((unsigned)f2bf(b) << 16);
-}
-template <> __device__ __forceinline__ void st2<float>(float* p, float a, float b) { *(float2*)p = make_float2(a, b); }
+#define DW_CC 64          // channels per workgroup
 
-template <typename T>
-__global__ void k_dwconv5(const T* __restrict__ x, const float* __restrict__ w,
-                          const float* __restrict__ bias, T* y, int H, int W, int C8, long n8, int flip,
-                          int acc) {
-    const int C = C8 * 8;
-    for (long i = blockIdx.x * 256L + threadIdx.x; i < n8; i += gridDim.x * 256L) {
-        int c0 = (int)(i % C8) * 8;
-        long p = i / C8;
-        int wo = (int)(p % W);
-        long q = p / W;
-        int ho = (int)(q % H);
-        long b = q / H;
-        float o[8];
-        if (acc) V8<T>::ld(y + i * 8, o);
-        else {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) o[j] = bias ? bias[c0 + j] : 0.f;
-        }
-        for (int kh = 0; kh < 5; ++kh) {
-            int hi = ho + kh - 2;
-            if (hi < 0 || hi >= H) continue;
-            for (int kw = 0; kw < 5; ++kw) {
-                int wi = wo + kw - 2;
-                if (wi < 0 || wi >= W) continue;
-                float v[8];
-                V8<T>::ld(x + (((b * H + hi) * (long)W + wi) * C + c0), v);
-                int tap = flip ? (4 - kh) * 5 + (4 - kw) : kh * 5 + kw;
-                const float* wp = w + (long)tap * C + c0;
-                float4 w0 = *(const float4*)wp, w1 = *(const float4*)(wp + 4);
-                o[0] += v[0] * w0.x; o[1] += v[1] * w0.y; o[2] += v[2] * w0.z; o[3] += v[3] * w0.w;
-                o[4] += v[4] * w1.x; o[5] += v[5] * w1.y; o[6] += v[6] * w1.z; o[7] += v[7] * w1.w;
-            }
-        }
-        V8<T>::st(y + i * 8, o);
+template <typename T> struct DwVec;     // 4 channels <-> float[4]
+template <> struct DwVec<bf16> {
+    static __device__ __forceinline__ void ld(const bf16* p, float (&v)[4]) {
+        const uint2 u = *(const uint2*)p;
+        v[0] = __uint_as_float(u.x << 16); v[1] = __uint_as_float(u.x & 0xffff0000u);
+        v[2] = __uint_as_float(u.y << 16); v[3] = __uint_as_float(u.y & 0xffff0000u);
+    }
+    static __device__ __forceinline__ void st(bf16* p, const float (&v)[4]) {
+        uint2 u;
+        u.x = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
+        u.y = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
+        *(uint2*)p = u;
+    }
+};
+template <> struct DwVec<float> {
+    static __device__ __forceinline__ void ld(const float* p, float (&v)[4]) {
+        const float4 u = *(const float4*)p;
+        v[0] = u.x; v[1] = u.y; v[2] = u.z; v[3] = u.w;
+    }
+    static __device__ __forceinline__ void st(float* p, const float (&v)[4]) {
+        *(float4*)p = make_float4(v[0], v[1], v[2], v[3]);
+    }
+};
+
+// Stage rows [y0, y0+NH) x cols [x0, x0+NW) x channels [c_base, c_base+64) of image b into LDS
+// ([pixel][64] T, zero outside the image / beyond C).
+template <typename T, int NH, int NW>
+__device__ __forceinline__ void dw_stage(T* __restrict__ s, const T* __restrict__ src, long b, int H, int W,
+                                         int C, int y0, int x0, int c_base) {
+    constexpr int VE = 16 / (int)sizeof(T);          // elements per 16-B chunk
+    constexpr int CPP = DW_CC / VE;                  // chunks per pixel
+    for (int q = threadIdx.x; q < NH * NW * CPP; q += 256) {
+        const int pix = q / CPP, cc = (q - pix * CPP) * VE;
+        const int py = pix / NW, px = pix - py * NW;
+        const int gy = y0 + py, gx = x0 + px;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (gy >= 0 && gy < H && gx >= 0 && gx < W && c_base + cc < C)
+            v = *(const uint4*)(src + (((b * H + gy) * (long)W + gx) * C + c_base + cc));
+        *(uint4*)(s + pix * DW_CC + cc) = v;
     }
 }
 
-// LDS-resident variant for H*W <= 64 (the 4x4 / 8x8 towers): a workgroup owns 128 channels of a chunk
-// of images; the [HW][128] input slab is staged in LDS once per image, each thread keeps the 25 taps of
-// its two channels in registers and produces the outputs of every 4th pixel.
-template <typename T>
-__global__ __launch_bounds__(256) void k_dwconv5_lds(const T* __restrict__ x, const float* __restrict__ w,
-                                                     const float* __restrict__ bias, T* y, int B, int H, int W,
-                                                     int C, int flip, int acc, int imgs_per_block) {
-    constexpr int CS = 128;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    T* sx = (T*)smem;
-    const int HW = H * W;
-    const int c_base = blockIdx.x * CS;
-    const int cp = threadIdx.x & 63, pg = threadIdx.x >> 6;
-    const int c = c_base + 2 * cp;
+// o[r] += sum over the 5x5 window of output (row0 + r, col) for R vertically adjacent outputs: each halo
+// row is read once (5 LDS reads of 4 channels) and feeds every output whose window contains it.
+template <typename T, int HTW, int R>
+__device__ __forceinline__ void dw5_rows(const T* __restrict__ sx, const float (&wr)[25][4], float (&o)[R][4],
+                                         int row0, int col, int cg) {
+#pragma unroll
+    for (int hr = 0; hr < R + 4; ++hr) {                 // halo row row0 + hr feeds outputs hr-4 .. hr
+        float xin[5][4];
+#pragma unroll
+        for (int kw = 0; kw < 5; ++kw) DwVec<T>::ld(sx + ((row0 + hr) * HTW + col + kw) * DW_CC + cg * 4, xin[kw]);
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int kh = hr - r;
+            if (kh < 0 || kh > 4) continue;
+#pragma unroll
+            for (int kw = 0; kw < 5; ++kw)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[r][j] += xin[kw][j] * wr[kh * 5 + kw][j];
+        }
+    }
+}
+
+template <typename T, int TH, int TW, int R>
+__global__ __launch_bounds__(256) void k_dw5_fwd(const T* __restrict__ x, const float* __restrict__ w,
+                                                 const float* __restrict__ bias, T* y, int H, int W, int C,
+                                                 int tiles_x, int flip, int acc) {
+    static_assert(TW * (TH / R) == 16 && TH % R == 0, "16 pixel lanes per workgroup");
+    constexpr int HTH = TH + 4, HTW = TW + 4;
+    __shared__ __attribute__((aligned(16))) T sx[HTH * HTW * DW_CC];
+    const int c_base = blockIdx.x * DW_CC;
+    const int ty = blockIdx.y / tiles_x, tx = blockIdx.y - ty * tiles_x;
+    const long b = blockIdx.z;
+    const int cg = threadIdx.x & 15, pl = threadIdx.x >> 4;
+    const int c = c_base + cg * 4;
     const bool cval = c < C;
-    float wr[25][2];
+    // taps of this thread's 4 channels (issued before the staging so both latencies overlap)
+    float wr[25][4];
 #pragma unroll
     for (int t = 0; t < 25; ++t) {
         const int tap = flip ? 24 - t : t;
-        wr[t][0] = cval ? w[(long)tap * C + c] : 0.f;
-        wr[t][1] = cval ? w[(long)tap * C + c + 1] : 0.f;
+        const float4 u = cval ? *(const float4*)(w + (long)tap * C + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        wr[t][0] = u.x; wr[t][1] = u.y; wr[t][2] = u.z; wr[t][3] = u.w;
     }
-    const float b0 = (bias && cval) ? bias[c] : 0.f, b1 = (bias && cval) ? bias[c + 1] : 0.f;
-    constexpr int VE = 16 / (int)sizeof(T);
-    const int chunks_per_row = CS / VE, nchunks = HW * chunks_per_row;
-    const int img0 = blockIdx.y * imgs_per_block;
-    int img1 = img0 + imgs_per_block;
-    if (img1 > B) img1 = B;
-    for (int b = img0; b < img1; ++b) {
-        __syncthreads();
-        for (int q = threadIdx.x; q < nchunks; q += 256) {
-            int p = q / chunks_per_row, cc = (q - p * chunks_per_row) * VE;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (c_base + cc < C) v = *(const uint4*)(x + ((long)b * HW + p) * C + c_base + cc);
-            *(uint4*)(sx + p * CS + cc) = v;
+    dw_stage<T, HTH, HTW>(sx, x, b, H, W, C, ty * TH - 2, tx * TW - 2, c_base);
+    __syncthreads();
+    if (!cval) return;
+    const int col = pl % TW, row0 = (pl / TW) * R;       // tile coordinates of the first output
+    const int gx = tx * TW + col;
+    float o[R][4];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int gy = ty * TH + row0 + r;
+        if (acc && gy < H && gx < W) DwVec<T>::ld(y + (((b * H + gy) * (long)W + gx) * C + c), o[r]);
+        else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[r][j] = (bias && !acc) ? bias[c + j] : 0.f;
         }
-        __syncthreads();
-        if (!cval) continue;
-        for (int p = pg; p < HW; p += 4) {
-            const int h = p / W, wv = p - h * W;
-            T* yp = y + ((long)b * HW + p) * C + c;
-            float a0 = b0, a1 = b1;
-            if (acc) ld2<T>(yp, a0, a1);
+    }
+    dw5_rows<T, TW + 4, R>(sx, wr, o, row0, col, cg);
 #pragma unroll
-            for (int kh = 0; kh < 5; ++kh) {
-                const int hi = h + kh - 2;
-                if (hi < 0 || hi >= H) continue;
+    for (int r = 0; r < R; ++r) {
+        const int gy = ty * TH + row0 + r;
+        if (gy < H && gx < W) DwVec<T>::st(y + (((b * H + gy) * (long)W + gx) * C + c), o[r]);
+    }
+}
+
+// bf16 production variant.  Persistent workgroups walk "units" (one 8x8 tile of one image, or four whole
+// 4x4 images); the halo of the next unit is in flight (LDS-DMA, global_load_lds_dwordx4: no VGPRs,
+// out-of-image chunks read a zero page) while the current one is computed, and the taps are loaded once
+// per workgroup.  Thread = channel PAIR (one 4-B LDS read, conflict-free across the 32 pairs of a strip)
+// x a 2-row x 4-column block of outputs: 48 halo reads feed 8 outputs (6 per output instead of 25), the
+// 25 x 2 taps + 16 accumulators fit in ~100 VGPRs, so four workgroups share a CU and hide each other's
+// LDS latency.  The FMAs compile to v_pk_fma_f32 on the channel pair.
+typedef float dw_f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ dw_f2 dw_unpack(unsigned v) {      // bf16 pair -> f32 pair
+    dw_f2 r;
+    r.x = __uint_as_float(v << 16); r.y = __uint_as_float(v & 0xffff0000u);
+    return r;
+}
+
+template <int TH, int TW, int IMGS>
+__global__ __launch_bounds__(256, 2) void k_dw5_fwd_ring(const bf16* __restrict__ x, const float* __restrict__ w,
+                                                      const float* __restrict__ bias, bf16* y, int B, int H,
+                                                      int W, int C, int tiles_x, int tiles_per_img, int flip,
+                                                      int acc, const uint4* __restrict__ zeros) {
+    static_assert(IMGS * (TH / 2) * (TW / 4) == 8, "8 pixel lanes of 2x4 outputs per workgroup");
+    constexpr int NS = 2;
+    constexpr int HTH = TH + 4, HTW = TW + 4, NCH = IMGS * HTH * HTW * 8;     // 16-B chunks per unit
+    constexpr int KI = (NCH + 255) / 256;            // DMA instructions per thread and stage
+    constexpr int STAGE = KI * 256;                  // chunks per stage (tail chunks read zeros)
+    __shared__ uint4 lds[NS * STAGE];
+    const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)lds;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c_base = blockIdx.x * DW_CC;
+    const int cp = tid & 31, pl = tid >> 5;
+    const int c = c_base + cp * 2;
+    const bool cval = c < C;
+    dw_f2 wr[25];
 #pragma unroll
-                for (int kw = 0; kw < 5; ++kw) {
-                    const int wi = wv + kw - 2;
-                    if (wi < 0 || wi >= W) continue;
-                    float x0, x1;
-                    ld2<T>(sx + (hi * W + wi) * CS + 2 * cp, x0, x1);
-                    a0 += x0 * wr[kh * 5 + kw][0];
-                    a1 += x1 * wr[kh * 5 + kw][1];
-                }
+    for (int t = 0; t < 25; ++t) {
+        const int tap = flip ? 24 - t : t;
+        const float2 u = cval ? *(const float2*)(w + (long)tap * C + c) : make_float2(0.f, 0.f);
+        wr[t].x = u.x; wr[t].y = u.y;
+    }
+    dw_f2 bv;
+    bv.x = (bias && !acc && cval) ? bias[c] : 0.f;
+    bv.y = (bias && !acc && cval) ? bias[c + 1] : 0.f;
+    const long units = IMGS == 1 ? (long)B * tiles_per_img : (long)(B + IMGS - 1) / IMGS;
+    const int nmine = blockIdx.y < units ? (int)((units - blockIdx.y + gridDim.y - 1) / gridDim.y) : 0;
+    auto unit_of = [&](int i, long& b, int& ty, int& tx) {      // first image and tile of unit i
+        const long u = blockIdx.y + (long)i * gridDim.y;
+        if (IMGS == 1) {
+            b = u / tiles_per_img;
+            const int tile = (int)(u - b * tiles_per_img);
+            ty = tile / tiles_x; tx = tile - ty * tiles_x;
+        } else {
+            b = u * IMGS; ty = 0; tx = 0;
+        }
+    };
+    auto issue = [&](int i) {
+        long b; int ty, tx;
+        unit_of(i, b, ty, tx);
+        const unsigned dst = lds_base + (unsigned)((i % NS) * STAGE) * 16u;
+#pragma unroll
+        for (int k = 0; k < KI; ++k) {
+            const int q = (k * 4 + wave) * 64 + lane;
+            const int pix = q >> 3, cc = (q & 7) * 8;
+            const int img = pix / (HTH * HTW), pi = pix - img * (HTH * HTW);
+            const int py = pi / HTW, px = pi - py * HTW;
+            const int gy = ty * TH - 2 + py, gx = tx * TW - 2 + px;
+            const bool ok = q < NCH && b + img < B && gy >= 0 && gy < H && gx >= 0 && gx < W && c_base + cc < C;
+            const void* p = ok ? (const void*)(x + ((((b + img) * H + gy) * (long)W + gx) * C + c_base + cc)) : (const void*)zeros;
+            glds16(p, dst + (unsigned)((k * 4 + wave) * 64) * 16u);
+        }
+    };
+    if (nmine > 0) issue(0);
+    // pixel lane -> (image within the unit, 2-row block, 4-column block)
+    constexpr int CB = TW / 4, RB = TH / 2;
+    const int cb = pl % CB, rb = (pl / CB) % RB, img = pl / (CB * RB);
+    for (int i = 0; i < nmine; ++i) {
+        wait_vmcnt<0>();             // this wave's part of unit i has landed (and its older y stores)
+        __syncthreads();             // everyone's part is in LDS; everyone finished reading stage (i+1) % 2
+        if (i + 1 < nmine) issue(i + 1);
+        long b; int ty, tx;
+        unit_of(i, b, ty, tx);
+        b += img;
+        const bf16* sx = (const bf16*)(lds + (i % NS) * STAGE) + (long)img * HTH * HTW * DW_CC;
+        const int gy0 = ty * TH + rb * 2, gx0 = tx * TW + cb * 4;
+        const bool live = cval && b < B;
+        dw_f2 o[2][4];
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                o[r][p] = bv;
+                if (acc && live && gy0 + r < H && gx0 + p < W)
+                    o[r][p] = dw_unpack(*(const unsigned*)(y + (((b * H + gy0 + r) * (long)W + gx0 + p) * C + c)));
             }
-            st2<T>(yp, a0, a1);
+#pragma unroll
+        for (int hr = 0; hr < 6; ++hr) {             // halo row rb*2 + hr feeds output rows hr-4 .. hr
+            dw_f2 xr[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                xr[q] = dw_unpack(*(const unsigned*)(sx + ((rb * 2 + hr) * HTW + cb * 4 + q) * DW_CC + cp * 2));
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const int kh = hr - r;
+                if (kh < 0 || kh > 4) continue;
+#pragma unroll
+                for (int p = 0; p < 4; ++p)
+#pragma unroll
+                    for (int kw = 0; kw < 5; ++kw)
+                        o[r][p] = __builtin_elementwise_fma(xr[p + kw], wr[kh * 5 + kw], o[r][p]);
+            }
+        }
+        if (live) {
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int p = 0; p < 4; ++p)
+                    if (gy0 + r < H && gx0 + p < W)
+                        *(unsigned*)(y + (((b * H + gy0 + r) * (long)W + gx0 + p) * C + c)) =
+                            (unsigned)f2bf(o[r][p].x) | ((unsigned)f2bf(o[r][p].y) << 16);
         }
     }
 }
@@ -122,155 +253,154 @@ __global__ __launch_bounds__(256) void k_dwconv5_lds(const T* __restrict__ x, co
 extern "C" int nvae_dwconv5(int dtype, const void* x, const float* w, const float* bias, void* y, int B,
                             int H, int W, int C, int flip, int accumulate, void* stream) {
     NVAE_REQUIRE(B > 0 && H > 0 && W > 0 && C >= 8 && C % 8 == 0, "dwconv5: bad shape");
-    NVAE_REQUIRE(aligned16(x) && aligned16(y) && aligned16(w), "dwconv5: alignment");
-    if (H * W <= 64) {
-        const int strips = cdiv(C, 128);
-        int want = 1024 / strips;
-        if (want < 1) want = 1;
-        int ipb = cdiv(B, want);
-        if (ipb < 1) ipb = 1;
-        dim3 grid(strips, cdiv(B, ipb));
-        DISPATCH_T(dtype, hipLaunchKernelGGL((k_dwconv5_lds<T>), grid, 256, (size_t)H * W * 128 * sizeof(T), (hipStream_t)stream, (const T*)x, w, bias, (T*)y, B, H, W, C, flip, accumulate, ipb);)
-        NVAE_LAUNCH_CHECK("dwconv5_lds");
+    NVAE_REQUIRE(aligned16(x) && aligned16(y) && aligned16(w) && (!bias || aligned16(bias)), "dwconv5: alignment");
+    const int strips = cdiv(C, DW_CC);
+    NVAE_REQUIRE(B <= 65535, "dwconv5: batch too large for the grid");
+    if (dtype == NVAE_BF16) {
+        const bool small = H <= 4 && W <= 4;
+        const int tx = small ? 1 : cdiv(W, 8), ty = small ? 1 : cdiv(H, 8);
+        const long units = small ? (B + 3) / 4 : (long)B * tx * ty;
+        long nb = 1024 / strips;         // 4 persistent workgroups per CU in flight
+        if (nb < 1) nb = 1;
+        if (nb > units) nb = units;
+        dim3 grid(strips, (unsigned)nb);
+        if (small)
+            hipLaunchKernelGGL((k_dw5_fwd_ring<4, 4, 4>), grid, 256, 0, (hipStream_t)stream, (const bf16*)x, w, bias, (bf16*)y, B, H, W, C, tx, tx * ty, flip, accumulate, zero_page());
+        else
+            hipLaunchKernelGGL((k_dw5_fwd_ring<8, 8, 1>), grid, 256, 0, (hipStream_t)stream, (const bf16*)x, w, bias, (bf16*)y, B, H, W, C, tx, tx * ty, flip, accumulate, zero_page());
+        NVAE_LAUNCH_CHECK("dwconv5");
         return NVAE_OK;
     }
-    long n8 = (long)B * H * W * (C / 8);
-    long g = (n8 + 255) / 256;
-    if (g > 4096) g = 4096;
-    DISPATCH_T(dtype, hipLaunchKernelGGL((k_dwconv5<T>), (int)g, 256, 0, (hipStream_t)stream, (const T*)x, w, bias, (T*)y, H, W, C / 8, n8, flip, accumulate);)
+    if (H <= 4 && W <= 4) {
+        dim3 grid(strips, 1, B);
+        DISPATCH_T(dtype, hipLaunchKernelGGL((k_dw5_fwd<T, 4, 4, 1>), grid, 256, 0, (hipStream_t)stream, (const T*)x, w, bias, (T*)y, H, W, C, 1, flip, accumulate);)
+    } else {
+        const int tx = cdiv(W, 8), ty = cdiv(H, 8);
+        NVAE_REQUIRE((long)tx * ty <= 65535 && B <= 65535, "dwconv5: image too large for the tile grid");
+        dim3 grid(strips, tx * ty, B);
+        DISPATCH_T(dtype, hipLaunchKernelGGL((k_dw5_fwd<T, 8, 8, 4>), grid, 256, 0, (hipStream_t)stream, (const T*)x, w, bias, (T*)y, H, W, C, tx, flip, accumulate);)
+    }
     NVAE_LAUNCH_CHECK("dwconv5");
     return NVAE_OK;
 }
 
 // dw[kh,kw,c] += sum_{b,h,w} x[b,h+kh-2,w+kw-2,c] * dy[b,h,w,c];  db[c] += sum dy.
-// Thread = one channel (lanes over consecutive channels: coalesced), block.y = chunk of images;
-// 25 taps + bias accumulate in registers, one atomic per (tap, channel) per block.
-template <typename T>
-__global__ void k_dwconv5_wgrad(const T* __restrict__ x, const T* __restrict__ dy, float* dw, float* db,
-                                int B, int H, int W, int C, int imgs_per_block) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= C) return;
-    const int b0 = blockIdx.y * imgs_per_block;
-    int b1 = b0 + imgs_per_block;
-    if (b1 > B) b1 = B;
-    float acc[25];
-#pragma unroll
-    for (int t = 0; t < 25; ++t) acc[t] = 0.f;
-    float ab = 0.f;
-    for (int b = b0; b < b1; ++b)
-        for (int h = 0; h < H; ++h)
-            for (int wv = 0; wv < W; ++wv) {
-                float g = ldf<T>(dy + (((long)b * H + h) * W + wv) * C + c);
-                ab += g;
-#pragma unroll
-                for (int kh = 0; kh < 5; ++kh) {
-                    int hi = h + kh - 2;
-                    if (hi < 0 || hi >= H) continue;
-#pragma unroll
-                    for (int kw = 0; kw < 5; ++kw) {
-                        int wi = wv + kw - 2;
-                        if (wi < 0 || wi >= W) continue;
-                        acc[kh * 5 + kw] += g * ldf<T>(x + (((long)b * H + hi) * W + wi) * C + c);
-                    }
-                }
-            }
-#pragma unroll
-    for (int t = 0; t < 25; ++t) atomicAdd(dw + (long)t * C + c, acc[t]);
-    if (db) atomicAdd(db + c, ab);
-}
-
-// LDS-resident variant for the shapes on the path (H*W <= 64): a workgroup owns 128 channels and a
-// chunk of images; per image the [HW][128] slabs of x and dy are staged in LDS once and every
-// (tap, channel) product reads them from there.  Thread = channel pair x tap group (taps tg, tg+4, ..),
-// lanes over consecutive channel pairs (conflict-free 4-B LDS reads).
-template <typename T>
-__global__ __launch_bounds__(256) void k_dwconv5_wgrad_lds(const T* __restrict__ x, const T* __restrict__ dy,
-                                                           float* dw, float* db, int B, int H, int W, int C,
-                                                           int imgs_per_block) {
-    constexpr int CS = 128;                        // channels per workgroup
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int HW = H * W;
+// PX = dy pixels per thread (adjacent in a row): 4 for 8x8 tiles, 1 for 4x4 tiles.
+template <typename T, int TH, int TW, int PX>
+__global__ __launch_bounds__(256) void k_dw5_wgrad(const T* __restrict__ x, const T* __restrict__ dy,
+                                                   float* dw, float* db, int B, int H, int W, int C,
+                                                   int tiles_x, int tiles_per_img, int units_per_block) {
+    static_assert(TH * TW == 16 * PX && TW % PX == 0, "16 pixel lanes per workgroup");
+    constexpr int HTH = TH + 4, HTW = TW + 4;
+    constexpr int SX = HTH * HTW * DW_CC, SD = TH * TW * DW_CC;
+    constexpr int RED_BYTES = 4 * 16 * 104 * 4;        // cross-wave reduction buffer
+    constexpr int STG_BYTES = (SX + SD) * (int)sizeof(T);
+    __shared__ __attribute__((aligned(16))) unsigned char smem[STG_BYTES > RED_BYTES ? STG_BYTES : RED_BYTES];
     T* sx = (T*)smem;
-    T* sdy = sx + HW * CS;
-    const int c_base = blockIdx.x * CS;
-    const int cp = threadIdx.x & 63, tg = threadIdx.x >> 6;      // channel pair, tap group
-    const int b0 = blockIdx.y * imgs_per_block;
-    int b1 = b0 + imgs_per_block;
-    if (b1 > B) b1 = B;
-    float acc[7][2];
+    T* sd = sx + SX;
+    const int c_base = blockIdx.x * DW_CC;
+    const int cg = threadIdx.x & 15, pl = threadIdx.x >> 4;
+    const int row = pl / (TW / PX), col0 = (pl % (TW / PX)) * PX;
+    float acc[25][4];
 #pragma unroll
-    for (int t = 0; t < 7; ++t) acc[t][0] = acc[t][1] = 0.f;
-    float ab0 = 0.f, ab1 = 0.f;
-    constexpr int VE = 16 / sizeof(T);
-    const int chunks_per_row = CS / VE;
-    const int nchunks = HW * chunks_per_row;
-    for (int b = b0; b < b1; ++b) {
+    for (int t = 0; t < 25; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[t][j] = 0.f;
+    float ab[4] = {0.f, 0.f, 0.f, 0.f};
+    const long units = (long)B * tiles_per_img;          // (image, tile) pairs
+    long u0 = (long)blockIdx.y * units_per_block, u1 = u0 + units_per_block;
+    if (u1 > units) u1 = units;
+    for (long u = u0; u < u1; ++u) {
+        const long b = u / tiles_per_img;
+        const int tile = (int)(u - b * tiles_per_img);
+        const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
         __syncthreads();
-        for (int q = threadIdx.x; q < nchunks; q += 256) {
-            int p = q / chunks_per_row, cc = (q - p * chunks_per_row) * VE;
-            uint4 vx = make_uint4(0, 0, 0, 0), vd = make_uint4(0, 0, 0, 0);
-            if (c_base + cc < C) {
-                long off = ((long)b * HW + p) * C + c_base + cc;
-                vx = *(const uint4*)(x + off);
-                vd = *(const uint4*)(dy + off);
-            }
-            *(uint4*)(sx + p * CS + cc) = vx;
-            *(uint4*)(sdy + p * CS + cc) = vd;
+        dw_stage<T, HTH, HTW>(sx, x, b, H, W, C, ty * TH - 2, tx * TW - 2, c_base);
+        dw_stage<T, TH, TW>(sd, dy, b, H, W, C, ty * TH, tx * TW, c_base);
+        __syncthreads();
+        float g[PX][4];
+#pragma unroll
+        for (int p = 0; p < PX; ++p) {
+            DwVec<T>::ld(sd + (row * TW + col0 + p) * DW_CC + cg * 4, g[p]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) ab[j] += g[p][j];
         }
-        __syncthreads();
-        for (int p = 0; p < HW; ++p) {
-            const int h = p / W, wv = p - h * W;
-            float g0, g1;
-            ld2<T>(sdy + p * CS + 2 * cp, g0, g1);
-            if (tg == 0) { ab0 += g0; ab1 += g1; }
 #pragma unroll
-            for (int t = 0; t < 7; ++t) {
-                const int tap = tg + 4 * t;
-                if (tap >= 25) continue;
-                const int kh = tap / 5, kw = tap - kh * 5;
-                const int hi = h + kh - 2, wi = wv + kw - 2;
-                if (hi < 0 || hi >= H || wi < 0 || wi >= W) continue;
-                float x0, x1;
-                ld2<T>(sx + (hi * W + wi) * CS + 2 * cp, x0, x1);
-                acc[t][0] += g0 * x0;
-                acc[t][1] += g1 * x1;
-            }
+        for (int kh = 0; kh < 5; ++kh) {
+            float xr[PX + 4][4];
+#pragma unroll
+            for (int q = 0; q < PX + 4; ++q) DwVec<T>::ld(sx + ((row + kh) * HTW + col0 + q) * DW_CC + cg * 4, xr[q]);
+#pragma unroll
+            for (int p = 0; p < PX; ++p)
+#pragma unroll
+                for (int kw = 0; kw < 5; ++kw)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[kh * 5 + kw][j] += g[p][j] * xr[p + kw][j];
         }
     }
-    const int c = c_base + 2 * cp;
-    if (c < C) {
+    // reduce over the 16 pixel lanes: lanes with equal cg are 16 apart (4 per wave), then 4 waves via LDS
 #pragma unroll
-        for (int t = 0; t < 7; ++t) {
-            const int tap = tg + 4 * t;
-            if (tap >= 25) continue;
-            atomicAdd(dw + (long)tap * C + c, acc[t][0]);
-            atomicAdd(dw + (long)tap * C + c + 1, acc[t][1]);
+    for (int t = 0; t < 25; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float v = acc[t][j];
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            acc[t][j] = v;
         }
-        if (db && tg == 0) { atomicAdd(db + c, ab0); atomicAdd(db + c + 1, ab1); }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float v = ab[j];
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 32, 64);
+        ab[j] = v;
+    }
+    __syncthreads();                                     // staging buffers are dead: reuse as [4][16][104] f32
+    float* red = (float*)smem;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane < 16) {
+        float* r = red + (wave * 16 + lane) * 104;
+#pragma unroll
+        for (int t = 0; t < 25; ++t)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) r[t * 4 + j] = acc[t][j];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) r[100 + j] = ab[j];
+    }
+    __syncthreads();
+    // 16 cg x 104 values: value e = t*4 + j of channel group g -> dw[t][c_base + 4g + j]
+    for (int q = threadIdx.x; q < 16 * 104; q += 256) {
+        const int gq = q / 104, e = q - gq * 104;
+        const float v = red[(0 * 16 + gq) * 104 + e] + red[(1 * 16 + gq) * 104 + e] +
+                        red[(2 * 16 + gq) * 104 + e] + red[(3 * 16 + gq) * 104 + e];
+        const int cc = c_base + gq * 4 + (e & 3);
+        if (cc >= C) continue;
+        if (e < 100) atomicAdd(dw + (long)(e >> 2) * C + cc, v);
+        else if (db) atomicAdd(db + cc, v);
     }
 }
 
 extern "C" int nvae_dwconv5_wgrad(int dtype, const void* x, const void* dy, float* dw, float* db, int B,
                                   int H, int W, int C, void* stream) {
-    NVAE_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && x && dy && dw, "dwconv5_wgrad: bad args");
-    if (H * W <= 64 && C % 8 == 0 && aligned16(x) && aligned16(dy)) {
-        const int strips = cdiv(C, 128);
-        int want = 768 / strips;
-        if (want < 1) want = 1;
-        int ipb = cdiv(B, want);
-        if (ipb < 1) ipb = 1;
-        dim3 grid(strips, cdiv(B, ipb));
-        DISPATCH_T(dtype, hipLaunchKernelGGL((k_dwconv5_wgrad_lds<T>), grid, 256, (size_t)2 * H * W * 128 * sizeof(T), (hipStream_t)stream, (const T*)x, (const T*)dy, dw, db, B, H, W, C, ipb);)
-        NVAE_LAUNCH_CHECK("dwconv5_wgrad_lds");
-        return NVAE_OK;
-    }
-    int cblocks = cdiv(C, 256);
-    int want = 512 / cblocks;
+    NVAE_REQUIRE(B > 0 && H > 0 && W > 0 && C >= 8 && C % 8 == 0 && x && dy && dw, "dwconv5_wgrad: bad args");
+    NVAE_REQUIRE(aligned16(x) && aligned16(dy), "dwconv5_wgrad: alignment");
+    const int strips = cdiv(C, DW_CC);
+    const bool small = H <= 4 && W <= 4;
+    const int tx = small ? 1 : cdiv(W, 8), ty = small ? 1 : cdiv(H, 8);
+    const long units = (long)B * tx * ty;
+    // ~1024 workgroups; every (tap, channel) address then receives <= 1024/strips atomic adds
+    long want = 1024 / strips;
     if (want < 1) want = 1;
-    int ipb = cdiv(B, want);
-    if (ipb < 1) ipb = 1;
-    dim3 grid(cblocks, cdiv(B, ipb));
-    DISPATCH_T(dtype, hipLaunchKernelGGL((k_dwconv5_wgrad<T>), grid, 256, 0, (hipStream_t)stream, (const T*)x, (const T*)dy, dw, db, B, H, W, C, ipb);)
+    long upb = (units + want - 1) / want;
+    if (upb < 1) upb = 1;
+    const long chunks = (units + upb - 1) / upb;
+    NVAE_REQUIRE(chunks <= 65535, "dwconv5_wgrad: too many tiles");
+    dim3 grid(strips, (unsigned)chunks);
+    if (small) {
+        DISPATCH_T(dtype, hipLaunchKernelGGL((k_dw5_wgrad<T, 4, 4, 1>), grid, 256, 0, (hipStream_t)stream, (const T*)x, (const T*)dy, dw, db, B, H, W, C, tx, tx * ty, (int)upb);)
+    } else {
+        DISPATCH_T(dtype, hipLaunchKernelGGL((k_dw5_wgrad<T, 8, 8, 4>), grid, 256, 0, (hipStream_t)stream, (const T*)x, (const T*)dy, dw, db, B, H, W, C, tx, tx * ty, (int)upb);)
+    }
     NVAE_LAUNCH_CHECK("dwconv5_wgrad");
     return NVAE_OK;
 }

@@ -82,5 +82,79 @@ def load_mnist(batch_size: int, binary: bool = True, data_dir: Optional[str] = N
     return Batches(tr, trl, batch_size, binary), Batches(te, tel, batch_size, binary)
 
 
-def load_celeba():   # datasets.py:23-25 is an empty stub in the reference too
-    raise NotImplementedError("the reference has no CelebA loader (datasets.py:23-25)")
+# ---- RGB data (BASELINE.json configs[3] / configs[4]; the reference has only stubs: datasets.py:23-25) ----
+class RgbBatches:
+    """Re-iterable (images [B,H,W,3] f32 = k/255, labels) batches from a uint8 [N,H,W,3] array."""
+
+    def __init__(self, images: np.ndarray, labels: np.ndarray, batch_size: int):
+        assert images.dtype == np.uint8 and images.ndim == 4 and images.shape[3] == 3
+        self.images, self.labels, self.batch_size = images, labels, batch_size
+
+    def __len__(self):
+        return (len(self.images) + self.batch_size - 1) // self.batch_size
+
+    def take(self, n):
+        return RgbBatches(self.images[:n * self.batch_size], self.labels[:n * self.batch_size], self.batch_size)
+
+    def __iter__(self) -> Iterator[Tuple[torch.Tensor, torch.Tensor]]:
+        for i in range(0, len(self.images), self.batch_size):
+            img = torch.from_numpy(self.images[i:i + self.batch_size].astype(np.float32)) / 255.0
+            yield img, torch.from_numpy(self.labels[i:i + self.batch_size].astype(np.int64))
+
+
+def synthetic_rgb(n: int, hw: int, seed: int = 1) -> Tuple[np.ndarray, np.ndarray]:
+    """uint8 [n,hw,hw,3]: smooth random colour fields plus noise, clipped so that 0 and 255 occur."""
+    g = np.random.default_rng(seed)
+    low = g.random((n, max(hw // 8, 1), max(hw // 8, 1), 3))
+    img = np.repeat(np.repeat(low, 8, axis=1), 8, axis=2)[:, :hw, :hw]
+    img = (img - 0.5) * 2.2 + 0.5 + 0.05 * g.standard_normal(img.shape)
+    return np.round(np.clip(img, 0, 1) * 255).astype(np.uint8), g.integers(0, 10, n).astype(np.uint8)
+
+
+def _read_cifar_bin(path: str) -> Tuple[np.ndarray, np.ndarray]:
+    """CIFAR-10 binary version: records of 1 label byte + 3072 pixel bytes (planar R, G, B)."""
+    raw = np.fromfile(path, dtype=np.uint8)
+    if raw.size % 3073:
+        raise ValueError(f"{path}: size {raw.size} is not a multiple of 3073")
+    rec = raw.reshape(-1, 3073)
+    return rec[:, 1:].reshape(-1, 3, 32, 32).transpose(0, 2, 3, 1).copy(), rec[:, 0].copy()
+
+
+def load_cifar10(batch_size: int, data_dir: Optional[str] = None, synthetic: bool = False,
+                 synthetic_sizes=(50000, 10000)):
+    """(train, test) RGB batches from <data_dir>/cifar10.npz (x_train, y_train, x_test, y_test) or the
+    binary distribution (data_batch_[1-5].bin, test_batch.bin).  Python-pickle batches are not read."""
+    data_dir = data_dir or os.environ.get("CIFAR10_DIR", "data/cifar10")
+    if synthetic:
+        (tr, trl), (te, tel) = synthetic_rgb(synthetic_sizes[0], 32, 1), synthetic_rgb(synthetic_sizes[1], 32, 2)
+        return RgbBatches(tr, trl, batch_size), RgbBatches(te, tel, batch_size)
+    npz = os.path.join(data_dir, "cifar10.npz")
+    if os.path.exists(npz):
+        d = np.load(npz)
+        return (RgbBatches(d["x_train"], d["y_train"].reshape(-1), batch_size),
+                RgbBatches(d["x_test"], d["y_test"].reshape(-1), batch_size))
+    parts = [_find(data_dir, [f"data_batch_{i}.bin"]) for i in range(1, 6)]
+    test = _find(data_dir, ["test_batch.bin"])
+    if test is None or any(x is None for x in parts):
+        raise FileNotFoundError(f"CIFAR-10 not found under {data_dir} (cifar10.npz or the *.bin files); there is "
+                                "no network here - pass --synthetic for random data of the same shape")
+    tr = [_read_cifar_bin(x) for x in parts]
+    te, tel = _read_cifar_bin(test)
+    return (RgbBatches(np.concatenate([a for a, _ in tr]), np.concatenate([b for _, b in tr]), batch_size),
+            RgbBatches(te, tel, batch_size))
+
+
+def load_celeba64(batch_size: int, data_dir: Optional[str] = None, synthetic: bool = False,
+                  synthetic_sizes=(4096, 512)):
+    """(train, test) 64x64 RGB batches from <data_dir>/celeba64.npz (x_train, x_test uint8 [N,64,64,3]);
+    BASELINE.json's configuration is "CelebA-64 synthetic", which `synthetic=True` provides."""
+    data_dir = data_dir or os.environ.get("CELEBA64_DIR", "data/celeba64")
+    if synthetic:
+        (tr, trl), (te, tel) = synthetic_rgb(synthetic_sizes[0], 64, 1), synthetic_rgb(synthetic_sizes[1], 64, 2)
+        return RgbBatches(tr, trl, batch_size), RgbBatches(te, tel, batch_size)
+    npz = os.path.join(data_dir, "celeba64.npz")
+    if not os.path.exists(npz):
+        raise FileNotFoundError(f"{npz} not found; there is no network here - pass --synthetic")
+    d = np.load(npz)
+    z = lambda a: np.zeros(len(a), np.uint8)
+    return RgbBatches(d["x_train"], z(d["x_train"]), batch_size), RgbBatches(d["x_test"], z(d["x_test"]), batch_size)

@@ -16,7 +16,8 @@ def neg_log_likelihood(model, test_data, n_attempts: int = 10) -> Metric:
         logs = []
         for _ in range(n_attempts):
             reconstruction, _, log_p, log_q = model(batch, nll=True)
-            recon = model.calculate_recon_loss(batch, reconstruction, crop_output=True)   # 28x28 crop (Q5)
+            # 28x28 crop of the zero-padded MNIST image (Q5); RGB data sets are not padded
+            recon = model.calculate_recon_loss(batch, reconstruction, crop_output=model.head == "bernoulli")
             logs.append(-recon - log_q + log_p)
         nll = -(torch.logsumexp(torch.stack(logs), dim=0) - math.log(float(n_attempts))).mean()
         nlls.append(float(nll))

@@ -92,7 +92,7 @@ def sample(args, model):
 
 def main(args):
     from . import parallel
-    from .datasets import load_mnist
+    from .datasets import load_celeba64, load_cifar10, load_mnist
     from .models import NVAE
     print(f"Args: {args}")
     rank, world, local = parallel.init_from_env()
@@ -101,8 +101,16 @@ def main(args):
                          "(the CPU oracle under oracle/ is test infrastructure only)")
     torch.cuda.set_device(local)
     torch.manual_seed(args.seed); random.seed(args.seed); np.random.seed(args.seed)
-    train_data, test_data = load_mnist(args.batch_size, binary=args.mode == "train" or args.binary_eval,
-                                       data_dir=args.data_dir, synthetic=args.synthetic)
+    if args.dataset == "mnist":
+        train_data, test_data = load_mnist(args.batch_size, binary=args.mode == "train" or args.binary_eval,
+                                           data_dir=args.data_dir, synthetic=args.synthetic)
+        hwc = [32, 32, 1]
+    elif args.dataset == "cifar10":
+        train_data, test_data = load_cifar10(args.batch_size, data_dir=args.data_dir, synthetic=args.synthetic)
+        hwc = [32, 32, 3]
+    else:
+        train_data, test_data = load_celeba64(args.batch_size, data_dir=args.data_dir, synthetic=args.synthetic)
+        hwc = [64, 64, 3]
     if args.debug:
         train_data, test_data = train_data.take(4), test_data.take(4)
     batches_per_epoch = len(train_data)
@@ -113,7 +121,8 @@ def main(args):
                  n_postprocess_blocks=args.n_postprocess_blocks, n_post_process_cells=args.n_postprocess_cells,
                  sr_lambda=args.sr_lambda, scale_factor=args.scale_factor, total_epochs=args.epochs,
                  n_total_iterations=batches_per_epoch * args.epochs, step_based_warmup=args.step_based_warmup,
-                 input_shape=[args.batch_size // world, 32, 32, 1], device=f"cuda:{local}",
+                 input_shape=[args.batch_size // world] + hwc, device=f"cuda:{local}",
+                 num_mixture_dec=args.num_mixture_dec,
                  dtype=torch.bfloat16 if args.dtype == "bf16" else torch.float32, seed=args.seed + rank,
                  lr_decay_steps=args.epochs * batches_per_epoch)
     model.tf_literal = args.tf_literal
@@ -148,7 +157,10 @@ def parse_args(argv=None):
     p.add_argument("--n_groups_per_scale", nargs="+", type=int, default=[5, 10])
     p.add_argument("--sr_lambda", type=float, default=0.01, help="Spectral regularisation strength")
     p.add_argument("--scale_factor", type=int, default=2)
-    p.add_argument("--dataset", type=str, choices=["mnist"], default="mnist")
+    p.add_argument("--dataset", type=str, choices=["mnist", "cifar10", "celeba64"], default="mnist",
+                   help="mnist is the reference's only data set; cifar10 / celeba64 use the RGB "
+                        "mixture-of-logistics head (nvae_tf_amd/configs.py lists the paper's shapes)")
+    p.add_argument("--num_mixture_dec", type=int, default=10, help="Logistic mixtures of the RGB output head")
     p.add_argument("--cpu", action="store_true", help="(reference flag) not supported: no CPU path")
     p.add_argument("--debug", action="store_true", help="Use only the first four batches of data")
     p.add_argument("--n_samples", type=int, default=10)

@@ -135,3 +135,18 @@ def test_train_cli_modes(lib, dev, tmp_path, capsys):
     train.main(train.parse_args(["--mode", "sample", "--epochs", "2", "--resume_from", "1", "--n_samples", "16"] + common))
     for t in ("t_0.7", "t_0.8", "t_0.9", "t_1.0"):
         assert len(list((tmp_path / "results" / t).iterdir())) == 16
+
+
+def test_train_cli_cifar10_synthetic(lib, dev, tmp_path, capsys):
+    """--dataset cifar10 end to end on synthetic RGB data: train (graph replay), checkpoint, IWAE NLL, samples."""
+    from nvae_tf_amd import train
+    common = ["--dataset", "cifar10", "--synthetic", "--batch_size", "8", "--n_encoder_channels", "16",
+              "--n_decoder_channels", "16", "--n_groups_per_scale", "3", "--n_preprocess_blocks", "1",
+              "--n_postprocess_blocks", "1", "--n_preprocess_cells", "2", "--n_postprocess_cells", "2",
+              "--model_save_dir", str(tmp_path / "models"), "--sample_dir", str(tmp_path / "results"),
+              "--dtype", "bf16", "--debug", "--step_based_warmup"]
+    train.main(train.parse_args(["--mode", "train", "--epochs", "1", "--model_save_frequency", "1",
+                                 "--sample_frequency", "1"] + common))
+    assert (tmp_path / "models" / "epoch_final.pt").exists()
+    train.main(train.parse_args(["--mode", "test", "--epochs", "1"] + common))
+    assert "Negative log likelihood" in capsys.readouterr().out

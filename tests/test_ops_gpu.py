@@ -306,17 +306,21 @@ def test_se_residual(lib, dev, dtype, shape, ss, bs):
 
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
-def test_dwconv5(lib, dev, dtype):
+@pytest.mark.parametrize("B,H,W_,C_", [(3, 8, 8, 96), (5, 4, 4, 1536), (2, 16, 16, 192), (2, 6, 10, 72), (3, 3, 2, 8),
+                                       (40, 32, 32, 64)],
+                         ids=["8x8", "4x4", "16x16", "ragged", "tiny", "many-tiles"])
+def test_dwconv5(lib, dev, dtype, B, H, W_, C_):
+    """Depthwise 5x5 forward / data gradient / weight + bias gradient at the tower shapes (4x4, 8x8),
+    multi-tile images, tiles and channel strips that are only partly inside the tensor."""
     from nvae_tf_amd import ops
     from nvae_tf_amd.ops import Var
     from nvae_tf_amd.params import ParamStore
     g = torch.Generator().manual_seed(17)
-    B, H, C_ = 3, 8, 96
     ps = ParamStore(seed=2)
     dw = ps.dw("dw", C_)
     ps.finalize(dev, dtype, zero_pool_floats=1 << 16)
     ps.get("dw.b").copy_(torch.randn(C_, generator=g))
-    x, dy = torch.randn(B, H, H, C_, generator=g), torch.randn(B, H, H, C_, generator=g)
+    x, dy = torch.randn(B, H, W_, C_, generator=g), torch.randn(B, H, W_, C_, generator=g)
     x64 = q(x, dtype).requires_grad_(True)
     w64 = ps.get("dw.w").cpu().double().requires_grad_(True)
     b64 = ps.get("dw.b").cpu().double().requires_grad_(True)
@@ -331,6 +335,11 @@ def test_dwconv5(lib, dev, dtype):
     tol = TOL[dtype]
     assert rel_err(y.t, y_ref) < tol and rel_err(xv.g, gr[0]) < tol
     assert rel_err(ps.get_grad("dw.w"), gr[1]) < tol and rel_err(ps.get_grad("dw.b"), gr[2]) < tol
+    # accumulate into an existing data gradient (flip = 1, accumulate = 1)
+    from nvae_tf_amd._lib import call, ptr
+    acc = xv.g.clone()
+    call("nvae_dwconv5", ctx.dt, ptr(y.g), ptr(ps.view(dw.w)), None, ptr(acc), B, H, W_, C_, 1, 1)
+    assert rel_err(acc, 2 * gr[0]) < 2 * tol
 
 
 def _softclamp5(x):
