@@ -380,6 +380,121 @@ __global__ __launch_bounds__(256) void k_dw5_wgrad(const T* __restrict__ x, cons
     }
 }
 
+// bf16 production variant of the weight gradient for images larger than 4x4: same persistent LDS-DMA
+// ring and thread layout as k_dw5_fwd_ring (channel pair x 2x4 block of dy pixels): per unit 48 reads
+// of the x halo + 8 of dy feed 200 packed FMAs into the thread's 25 tap-pair accumulators, which live in
+// registers across all the units the workgroup visits.
+__global__ __launch_bounds__(256, 2) void k_dw5_wgrad_ring(const bf16* __restrict__ x, const bf16* __restrict__ dy,
+                                                           float* dw, float* db, int B, int H, int W, int C,
+                                                           int tiles_x, int tiles_per_img,
+                                                           const uint4* __restrict__ zeros) {
+    constexpr int TH = 8, TW = 8, NS = 2;
+    constexpr int HTH = TH + 4, HTW = TW + 4;
+    constexpr int XCH = HTH * HTW * 8, DCH = TH * TW * 8;        // 16-B chunks: x halo, dy tile
+    constexpr int KX = (XCH + 255) / 256, KD = (DCH + 255) / 256;
+    constexpr int STAGE = (KX + KD) * 256;
+    constexpr int RED = 4 * 32 * 52 / 4;                         // reduction buffer in uint4
+    __shared__ uint4 lds[NS * STAGE > RED ? NS * STAGE : RED];
+    const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)lds;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c_base = blockIdx.x * DW_CC;
+    const int cp = tid & 31, pl = tid >> 5;
+    const int cb = pl & 1, rb = pl >> 1;
+    dw_f2 acc[25];
+#pragma unroll
+    for (int t = 0; t < 25; ++t) acc[t] = dw_f2{0.f, 0.f};
+    dw_f2 ab = {0.f, 0.f};
+    const long units = (long)B * tiles_per_img;
+    const int nmine = blockIdx.y < units ? (int)((units - blockIdx.y + gridDim.y - 1) / gridDim.y) : 0;
+    auto issue = [&](int i) {
+        const long u = blockIdx.y + (long)i * gridDim.y;
+        const long b = u / tiles_per_img;
+        const int tile = (int)(u - b * tiles_per_img);
+        const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+        const unsigned dst = lds_base + (unsigned)((i % NS) * STAGE) * 16u;
+#pragma unroll
+        for (int k = 0; k < KX; ++k) {
+            const int q = (k * 4 + wave) * 64 + lane;
+            const int pix = q >> 3, cc = (q & 7) * 8;
+            const int py = pix / HTW, px = pix - py * HTW;
+            const int gy = ty * TH - 2 + py, gx = tx * TW - 2 + px;
+            const bool ok = q < XCH && gy >= 0 && gy < H && gx >= 0 && gx < W && c_base + cc < C;
+            const void* p = ok ? (const void*)(x + (((b * H + gy) * (long)W + gx) * C + c_base + cc)) : (const void*)zeros;
+            glds16(p, dst + (unsigned)((k * 4 + wave) * 64) * 16u);
+        }
+#pragma unroll
+        for (int k = 0; k < KD; ++k) {
+            const int q = (k * 4 + wave) * 64 + lane;
+            const int pix = q >> 3, cc = (q & 7) * 8;
+            const int py = pix / TW, px = pix - py * TW;
+            const int gy = ty * TH + py, gx = tx * TW + px;
+            const bool ok = q < DCH && gy < H && gx < W && c_base + cc < C;
+            const void* p = ok ? (const void*)(dy + (((b * H + gy) * (long)W + gx) * C + c_base + cc)) : (const void*)zeros;
+            glds16(p, dst + (unsigned)(KX * 256 + (k * 4 + wave) * 64) * 16u);
+        }
+    };
+    if (nmine > 0) issue(0);
+    for (int i = 0; i < nmine; ++i) {
+        wait_vmcnt<0>();
+        __syncthreads();
+        if (i + 1 < nmine) issue(i + 1);
+        const bf16* sx = (const bf16*)(lds + (i % NS) * STAGE);
+        const bf16* sd = sx + KX * 256 * 8;
+        dw_f2 g[2][4];
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                g[r][p] = dw_unpack(*(const unsigned*)(sd + ((rb * 2 + r) * TW + cb * 4 + p) * DW_CC + cp * 2));
+                ab += g[r][p];
+            }
+#pragma unroll
+        for (int hr = 0; hr < 6; ++hr) {
+            dw_f2 xr[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                xr[q] = dw_unpack(*(const unsigned*)(sx + ((rb * 2 + hr) * HTW + cb * 4 + q) * DW_CC + cp * 2));
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const int kh = hr - r;
+                if (kh < 0 || kh > 4) continue;
+#pragma unroll
+                for (int p = 0; p < 4; ++p)
+#pragma unroll
+                    for (int kw = 0; kw < 5; ++kw)
+                        acc[kh * 5 + kw] = __builtin_elementwise_fma(g[r][p], xr[p + kw], acc[kh * 5 + kw]);
+            }
+        }
+    }
+    // reduce over the 8 pixel lanes: the two of a wave by shuffle, the four waves through LDS
+#pragma unroll
+    for (int t = 0; t < 25; ++t) {
+        acc[t].x += __shfl_xor(acc[t].x, 32, 64);
+        acc[t].y += __shfl_xor(acc[t].y, 32, 64);
+    }
+    ab.x += __shfl_xor(ab.x, 32, 64);
+    ab.y += __shfl_xor(ab.y, 32, 64);
+    __syncthreads();                                 // stages are dead: reuse as [4 waves][32 pairs][52] f32
+    float* red = (float*)lds;
+    if (lane < 32) {
+        float* r = red + (wave * 32 + lane) * 52;
+#pragma unroll
+        for (int t = 0; t < 25; ++t) { r[t * 2] = acc[t].x; r[t * 2 + 1] = acc[t].y; }
+        r[50] = ab.x; r[51] = ab.y;
+    }
+    __syncthreads();
+    for (int q = tid; q < 32 * 52; q += 256) {
+        const int pr = q / 52, e = q - pr * 52;
+        const float v = red[(0 * 32 + pr) * 52 + e] + red[(1 * 32 + pr) * 52 + e] + red[(2 * 32 + pr) * 52 + e] +
+                        red[(3 * 32 + pr) * 52 + e];
+        const int cc = c_base + pr * 2 + (e & 1);
+        if (cc >= C) continue;
+        if (e < 50) atomicAdd(dw + (long)(e >> 1) * C + cc, v);
+        else if (db) atomicAdd(db + cc, v);
+    }
+}
+
 extern "C" int nvae_dwconv5_wgrad(int dtype, const void* x, const void* dy, float* dw, float* db, int B,
                                   int H, int W, int C, void* stream) {
     NVAE_REQUIRE(B > 0 && H > 0 && W > 0 && C >= 8 && C % 8 == 0 && x && dy && dw, "dwconv5_wgrad: bad args");
@@ -388,14 +503,22 @@ extern "C" int nvae_dwconv5_wgrad(int dtype, const void* x, const void* dy, floa
     const bool small = H <= 4 && W <= 4;
     const int tx = small ? 1 : cdiv(W, 8), ty = small ? 1 : cdiv(H, 8);
     const long units = (long)B * tx * ty;
-    // ~1024 workgroups; every (tap, channel) address then receives <= 1024/strips atomic adds
-    long want = 1024 / strips;
+    // Each workgroup ends with one atomic per (tap, channel) of its strip, so its share of units must be
+    // worth that tail: >= 4 units per workgroup when that still fills the 256 CUs, at most ~1024 workgroups.
+    long want = units / (small ? 16 : 4);        // a 4x4 unit is only 16 pixels
+    if (want > 1024 / strips) want = 1024 / strips;
+    if (want < cdiv(256, strips)) want = cdiv(256, strips);
+    if (want > units) want = units;
     if (want < 1) want = 1;
     long upb = (units + want - 1) / want;
-    if (upb < 1) upb = 1;
     const long chunks = (units + upb - 1) / upb;
     NVAE_REQUIRE(chunks <= 65535, "dwconv5_wgrad: too many tiles");
     dim3 grid(strips, (unsigned)chunks);
+    if (dtype == NVAE_BF16 && !small) {
+        hipLaunchKernelGGL(k_dw5_wgrad_ring, grid, 256, 0, (hipStream_t)stream, (const bf16*)x, (const bf16*)dy, dw, db, B, H, W, C, tx, tx * ty, zero_page());
+        NVAE_LAUNCH_CHECK("dwconv5_wgrad");
+        return NVAE_OK;
+    }
     if (small) {
         DISPATCH_T(dtype, hipLaunchKernelGGL((k_dw5_wgrad<T, 4, 4, 1>), grid, 256, 0, (hipStream_t)stream, (const T*)x, (const T*)dy, dw, db, B, H, W, C, tx, tx * ty, (int)upb);)
     } else {
