@@ -73,6 +73,57 @@ def time_dominant_kernel(model, batch, iters=20):
     return out
 
 
+PEAK_HBM_GBPS = 8000.0           # MI355X_MICROARCH.md: HBM3E ~8 TB/s
+
+
+def time_hbm_kernels(model, batch, iters=30):
+    """The HBM-bound kernels of the decoder's depthwise-separable cell at this
+    workload's two tower shapes: algorithmic bytes (elements x bytes, reads + writes of the tensor) /
+    launch duration, measured with HIP events on the launch stream."""
+    from nvae_tf_amd import _lib as L
+    dev, dt = model.device, model.dtype
+    es = 2 if dt == torch.bfloat16 else 4
+    code = L.dtype_code(dt)
+    out = []
+    for hw, ch in ((4, 1536), (8, 768)):
+        x = torch.randn(batch, hw, hw, ch, device=dev).to(dt)
+        dy = torch.randn(batch, hw, hw, ch, device=dev).to(dt)
+        y = torch.empty_like(x)
+        w, b = torch.randn(25, ch, device=dev), torch.randn(ch, device=dev)
+        dw, db = torch.zeros(25, ch, device=dev), torch.zeros(ch, device=dev)
+        sc, sh = torch.rand(ch, device=dev) + 0.5, torch.randn(ch, device=dev)
+        k0k1 = torch.randn(2, ch, device=dev)
+        gate = torch.rand(batch, ch, device=dev)
+        rows, n = batch * hw * hw, x.numel()
+        cases = [
+            ("k_dw5_fwd_ring (depthwise 5x5 fwd/dgrad)", 2 * n * es,
+             lambda: L.call("nvae_dwconv5", code, L.ptr(x), L.ptr(w), L.ptr(b), L.ptr(y), batch, hw, hw, ch, 0, 0)),
+            ("k_dw5_wgrad (depthwise 5x5 weight gradient)", 2 * n * es,
+             lambda: L.call("nvae_dwconv5_wgrad", code, L.ptr(x), L.ptr(dy), L.ptr(dw), L.ptr(db), batch, hw, hw, ch)),
+            ("k_bn_apply (BN + Swish apply)", 2 * n * es,
+             lambda: L.call("nvae_bn_apply", code, L.ptr(x), L.ptr(y), rows, ch, L.ptr(sc), L.ptr(sh), L.ACT_SWISH)),
+            ("k_bn_bwd_apply (BN + Swish backward apply)", 3 * n * es,
+             lambda: L.call("nvae_bn_bwd_apply", code, L.ptr(x), L.ptr(dy), L.ptr(y), rows, ch, L.ptr(sc), L.ptr(sh),
+                            L.ptr(k0k1), L.ACT_SWISH, 0)),
+            ("k_se_apply (SE gate + residual)", 3 * n * es,
+             lambda: L.call("nvae_se_apply", code, L.ptr(x), L.ptr(dy), L.ptr(y), batch, hw * hw, ch, L.ptr(gate), 0.1, 1.0)),
+        ]
+        for name, nbytes, fn in cases:
+            for _ in range(3):
+                fn()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(iters):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            us = e0.elapsed_time(e1) * 1e3 / iters
+            gbps = nbytes / us / 1e3
+            out.append({"kernel": name, "shape": f"B{batch}x{hw}x{hw}x{ch}", "us": round(us, 2),
+                        "algorithmic_bytes": nbytes, "GB/s": round(gbps, 1), "frac_of_hbm_peak": round(gbps / PEAK_HBM_GBPS, 4)})
+    return out
+
+
 def cpu_baseline(seconds_budget=20.0):
     """The CPU oracle (PyTorch-CPU restatement of the reference arithmetic, f32, eager) timed on the
     host cores: same model (C2), a bounded sample of the workload (batch 8)."""
@@ -223,6 +274,7 @@ def main():
                          "traffic_unit": "bytes per launch (2*FETCH_SIZE + WRITE_SIZE, rocprofv3 --pmc)",
                          "algorithmic_bytes": 0.5 * (57704448 + 102506496),
                          "avg_launch_ms": avg_ms, "shapes": kern},
+            "hbm_kernels": time_hbm_kernels(model, args.batch),
         }
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline()

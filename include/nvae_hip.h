@@ -71,6 +71,25 @@ int nvae_conv_gemm_mtiles(int dtype, const NvaeConvGeom* g);
 int nvae_conv_gemm(int dtype, const NvaeConvGeom* g, const void* src, const void* wT, int w_ld,
                    const float* bias, const void* residual, void* out, int out_f32, float* stats,
                    void* stream);
+/* nvae_conv_gemm used as the DATA GRADIENT of a conv whose input was y = act(BN(x)) (the BNSwishConv /
+ * ConvBNSwish pairs, encoder.py:91-98, decoder.py:125-135, postprocess.py:84-107): `out` receives dy
+ * as usual and the epilogue additionally reduces dpre = dy * act'(scale*x + shift) against the same
+ * tile of x: partials[mtiles][2][Cout] <- (sum dpre, sum dpre*x), and the last M-tile of each column
+ * of tiles finishes dgamma += / dbeta += / k0k1 exactly as nvae_bn_bwd_reduce + nvae_bn_bwd_finalize
+ * would, so only nvae_bn_bwd_apply remains for that layer.  Requires 16-B aligned output rows and
+ * Cout % 8 == 0.  counters: >= ceil(Cout/64) ints, zero at rest (shared with nvae_bn_stats_fin); with
+ * counters == NULL the kernel only writes the slab and the caller runs nvae_bn_bwd_finalize_s with
+ * S = nvae_conv_gemm_mtiles (the faster arrangement: workgroups retire without waiting).          */
+typedef struct NvaeBnBwdFuse {
+    const void* x;          /* BN input [B*Hout*Wout, x_ld], activation dtype */
+    int x_ld, act, frozen;
+    const float* scale; const float* shift; const float* mean; const float* invstd;
+    float* partials; int* counters;
+    float* dgamma; float* dbeta; float* k0k1;
+} NvaeBnBwdFuse;
+int nvae_conv_gemm_bnbwd(int dtype, const NvaeConvGeom* g, const void* src, const void* wT, int w_ld,
+                         const float* bias, const void* residual, void* out, const NvaeBnBwdFuse* f,
+                         void* stream);
 /* Weight gradient: dw[k, n] += sum_m gather(x)[m, k] * dy[m, n]  (f32 atomics, dw zeroed or
  * holding a partial sum).  g describes the FORWARD conv; dy has pixel stride g->out_ld.
  * dw_ld = row stride of dw in floats.  db (may be NULL): db[n] += sum_m dy[m, n].
@@ -142,6 +161,11 @@ int nvae_bn_bwd_reduce_fin(int dtype, const void* x, const void* dy, long rows, 
                            const float* scale, const float* shift, const float* mean,
                            const float* invstd, int act, float* partials, int* counters,
                            float* dgamma, float* dbeta, float* k0k1, int frozen, void* stream);
+/* as nvae_bn_bwd_finalize for a slab with S row splits (S = nvae_conv_gemm_mtiles for the slab that
+ * nvae_conv_gemm_bnbwd leaves when it is given no counters)                                        */
+int nvae_bn_bwd_finalize_s(const float* partials, int S, long rows, int C, const float* scale,
+                           const float* mean, const float* invstd, float* dgamma, float* dbeta,
+                           float* k0k1, int frozen, void* stream);
 int nvae_bn_bwd_apply(int dtype, const void* x, const void* dy, void* dx, long rows, int C,
                       const float* scale, const float* shift, const float* k0k1, int act,
                       int accumulate, void* stream);
@@ -161,6 +185,10 @@ int nvae_se_gate_bwd(const float* r, const float* pooled_sum, const float* gate,
                      int B, int HW, int C, int Hd, const float* w1, const float* w2, float branch_scale,
                      float* dw1, float* db1, float* dw2, float* db2, float* dpool,
                      float* scratch /*[B*(C+Hd)]*/, void* stream);
+/* dw1 == NULL above skips the FC parameter gradients; nvae_se_wgrad computes them later from the same
+ * scratch (they do not feed the data-gradient chain: the host enqueues them on its side stream).   */
+int nvae_se_wgrad(const float* pooled_sum, const float* hidden, const float* scratch, int B, int HW,
+                  int C, int Hd, float* dw1, float* db1, float* dw2, float* db2, void* stream);
 int nvae_se_bwd_apply(int dtype, const void* dy, const float* gate, const float* dpool, void* dx,
                       void* dskip, int B, int HW, int C, float skip_scale, float branch_scale,
                       int acc_dx, int acc_dskip, void* stream);

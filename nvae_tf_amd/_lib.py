@@ -26,6 +26,13 @@ class ConvGeom(C.Structure):
                  "pad_l", "div", "exact", "in_ld", "out_ld", "res_ld")]
 
 
+class BnBwdFuse(C.Structure):     # NvaeBnBwdFuse
+    _fields_ = [("x", C.c_void_p), ("x_ld", C.c_int), ("act", C.c_int), ("frozen", C.c_int),
+                ("scale", C.c_void_p), ("shift", C.c_void_p), ("mean", C.c_void_p), ("invstd", C.c_void_p),
+                ("partials", C.c_void_p), ("counters", C.c_void_p),
+                ("dgamma", C.c_void_p), ("dbeta", C.c_void_p), ("k0k1", C.c_void_p)]
+
+
 class ConvDesc(C.Structure):
     _fields_ = [("w_off", C.c_longlong), ("wf_off", C.c_longlong), ("wd_off", C.c_longlong),
                 ("u_off", C.c_int), ("t_off", C.c_int), ("K", C.c_int), ("Cout", C.c_int),
@@ -40,6 +47,7 @@ _G = C.POINTER(ConvGeom)
 _SIGS = {
     "nvae_conv_gemm_mtiles": None,
     "nvae_conv_gemm": [_i, _G, _p, _p, _i, _p, _p, _p, _i, _p],
+    "nvae_conv_gemm_bnbwd": [_i, _p, _p, _p, _i, _p, _p, _p, _p],
     "nvae_conv_wgrad_scratch": None,
     "nvae_conv_wgrad": [_i, _G, _p, _p, _p, _i, _p, _p, _l],
     "nvae_conv_direct": [_i, _G, _p, _p, _l, _l, _l, _i, _p, _p, _p, _i],
@@ -57,12 +65,14 @@ _SIGS = {
     "nvae_bn_stats_fin": [_i, _p, _l, _i, _p, _p, _p, _p, _p, _p, _f, _f, _p, _p, _p, _p],
     "nvae_bn_bwd_reduce_fin": [_i, _p, _p, _l, _i, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p, _i],
     "nvae_bn_bwd_finalize": [_p, _l, _i, _p, _p, _p, _p, _p, _p, _i],
+    "nvae_bn_bwd_finalize_s": [_p, _i, _l, _i, _p, _p, _p, _p, _p, _p, _i],
     "nvae_bn_bwd_apply": [_i, _p, _p, _p, _l, _i, _p, _p, _p, _i, _i],
     "nvae_se_pool": [_i, _p, _i, _i, _i, _p],
     "nvae_se_gate": [_p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p],
     "nvae_se_apply": [_i, _p, _p, _p, _i, _i, _i, _p, _f, _f],
     "nvae_se_bwd_reduce": [_i, _p, _p, _i, _i, _i, _p],
     "nvae_se_gate_bwd": [_p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _f, _p, _p, _p, _p, _p, _p],
+    "nvae_se_wgrad": [_p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p],
     "nvae_se_bwd_apply": [_i, _p, _p, _p, _p, _p, _i, _i, _i, _f, _f, _i, _i],
     "nvae_unary_fwd": [_i, _i, _p, _p, _l, _f, _f],
     "nvae_unary_bwd": [_i, _i, _p, _p, _p, _l, _i],

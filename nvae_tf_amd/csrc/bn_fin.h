@@ -52,7 +52,7 @@ __device__ __forceinline__ bool bn_last_arriver(int* counter, int contributors) 
     return s_last != 0;
 }
 
-// Sum slabs for channels [cbase, cbase + 64) with a 256-thread workgroup.  The strip's slab rows
+// Sum slabs for channels [cbase, cbase + 64) with a workgroup of >= 256 threads.  The strip's slab rows
 // (row = 2*s + q, 64 floats each) are read as 16-B agent-scope loads, 16 rows in flight per thread, so
 // up to 128 splits cost ONE memory round trip (the loop form of this sum took 8).
 // Returns true with (c, s1, s2) valid in the 64 threads that own a channel < C.  C % 4 == 0.
@@ -62,10 +62,11 @@ __device__ __forceinline__ bool bn_slab_sum64(const float* partials, int S, int 
                                               float& s1, float& s2) {
     __shared__ float sm[16][64];
     const int fl = threadIdx.x & 15, rl = threadIdx.x >> 4;      // 16-B lane, row lane (q = rl & 1)
+    const bool worker = threadIdx.x < 256;                       // larger workgroups: the rest only meet the barriers
     const int cq = cbase + fl * 4;
     const int rows = 2 * S;
     bn_f4 acc = {0.f, 0.f, 0.f, 0.f};
-    if (cq < C) {
+    if (worker && cq < C) {
         // buffer loads with the sc1 (agent-coherent) cache policy: the compiler tracks their vmcnt
         const __amdgpu_buffer_rsrc_t rsrc =
             __builtin_amdgcn_make_buffer_rsrc((void*)partials, 0, (int)((long)rows * C * 4), 0x00020000);
@@ -83,8 +84,10 @@ __device__ __forceinline__ bool bn_slab_sum64(const float* partials, int S, int 
         }
     }
     __syncthreads();        // protects sm against the previous call's readers
+    if (worker) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) sm[rl][fl * 4 + j] = acc[j];
+        for (int j = 0; j < 4; ++j) sm[rl][fl * 4 + j] = acc[j];
+    }
     __syncthreads();
     c = cbase + (int)threadIdx.x;
     if (threadIdx.x >= 64 || c >= C) return false;

@@ -329,6 +329,18 @@ extern "C" int nvae_bn_bwd_reduce_fin(int dtype, const void* x, const void* dy, 
     return NVAE_OK;
 }
 
+// as nvae_bn_bwd_finalize for a slab with an explicit number of row splits (the conv-epilogue slab of
+// nvae_conv_gemm_bnbwd: S = nvae_conv_gemm_mtiles)
+extern "C" int nvae_bn_bwd_finalize_s(const float* partials, int S, long rows, int C, const float* scale,
+                                      const float* mean, const float* invstd, float* dgamma, float* dbeta,
+                                      float* k0k1, int frozen, void* stream) {
+    NVAE_REQUIRE(rows > 0 && C > 0 && S > 0 && partials && k0k1, "bn_bwd_finalize_s: bad args");
+    hipLaunchKernelGGL(k_bn_bwd_finalize, cdiv(C, 64), 256, 0, (hipStream_t)stream, partials, S,
+                       1.0f / (float)rows, C, scale, mean, invstd, dgamma, dbeta, k0k1, frozen);
+    NVAE_LAUNCH_CHECK("bn_bwd_finalize_s");
+    return NVAE_OK;
+}
+
 template <typename T>
 __global__ void k_bn_bwd_apply(const T* __restrict__ x, const T* __restrict__ dy, T* dx, long n8, int C8,
                                const float* __restrict__ scale, const float* __restrict__ shift,
@@ -546,8 +558,21 @@ extern "C" int nvae_se_gate_bwd(const float* r, const float* pooled_sum, const f
     float* dpre1 = scratch + (long)B * C;
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(k_se_gate_bwd, B, 256, 0, s, r, gate, hidden, 1.0f / (float)HW, C, Hd, w1, w2, branch_scale, dpre2, dpre1, dpool);
-    hipLaunchKernelGGL(k_se_wgrad, cdiv((long)Hd * C + C + Hd, 32), 256, 0, s, pooled_sum, hidden, dpre2, dpre1, B, 1.0f / (float)HW, C, Hd, dw1, db1, dw2, db2);
+    if (dw1)
+        hipLaunchKernelGGL(k_se_wgrad, cdiv((long)Hd * C + C + Hd, 32), 256, 0, s, pooled_sum, hidden, dpre2, dpre1, B, 1.0f / (float)HW, C, Hd, dw1, db1, dw2, db2);
     NVAE_LAUNCH_CHECK("se_gate_bwd");
+    return NVAE_OK;
+}
+
+// The parameter gradients of the two FC layers from the scratch nvae_se_gate_bwd left (dw1 == NULL
+// there): independent of the data-gradient chain, so the caller may enqueue it on another stream.
+extern "C" int nvae_se_wgrad(const float* pooled_sum, const float* hidden, const float* scratch, int B, int HW,
+                             int C, int Hd, float* dw1, float* db1, float* dw2, float* db2, void* stream) {
+    NVAE_REQUIRE(B > 0 && HW > 0 && C > 0 && C <= SE_MAX_C && Hd > 0 && Hd <= SE_MAX_H, "se_wgrad: bad shape C=%d Hd=%d", C, Hd);
+    NVAE_REQUIRE(pooled_sum && hidden && scratch && dw1 && db1 && dw2 && db2, "se_wgrad: NULL argument");
+    hipLaunchKernelGGL(k_se_wgrad, cdiv((long)Hd * C + C + Hd, 32), 256, 0, (hipStream_t)stream, pooled_sum, hidden,
+                       scratch, scratch + (long)B * C, B, 1.0f / (float)HW, C, Hd, dw1, db1, dw2, db2);
+    NVAE_LAUNCH_CHECK("se_wgrad");
     return NVAE_OK;
 }
 

@@ -19,14 +19,29 @@
 //   (bf16) when the fragments are read.  The reduction over M is split across blockIdx.y and
 //   combined with f32 atomics into the (zeroed) flat gradient buffer.
 #include "conv_common.h"
+#include "bn_fin.h"
 
 // Shared epilogue of the forward / data-gradient kernels.  `row_m(r)` maps a tile-local output row to
 // its global pixel index (or -1 if it does not exist); `lds_f` is the (no longer read) staging ring.
+// Fused BatchNorm-backward reduction (nvae_conv_gemm_bnbwd): this launch computes the data gradient dy of
+// a conv whose INPUT was y = act(BN(x)).  The epilogue, which holds the finished dy tile anyway, also
+// forms dpre = dy * act'(scale*x + shift) against the matching tile of x and emits the per-tile column
+// sums (sum dpre, sum dpre*x) as a [m_tiles][2][C] slab; the last M-tile of each N-tile column to arrive
+// turns the slab into dgamma / dbeta / k0,k1 (bn_fin.h).  The separate read of x and dy by
+// nvae_bn_bwd_reduce disappears; nvae_bn_bwd_apply follows as before.
+struct ConvBnBwd {
+    const void* x;          // BN input, [M, x_ld] in the activation dtype; nullptr = no fusion
+    int x_ld, act, m_tiles;
+    const float* scale; const float* shift;
+    float* partials;
+    BnFinArgs fin;
+};
+
 template <typename T, int BM, int BN, int WM, int WN, typename RowMap>
 __device__ __forceinline__ void conv_epilogue(f32x4 (&acc)[BM / WM / 16][BN / WN / 16], float* lds_f,
                                               const NvaeConvGeom& g, const float* __restrict__ bias,
                                               const T* residual, void* out, int out_f32, int bm, int bn,
-                                              float* stats, int vec_epi, RowMap row_m) {
+                                              float* stats, int vec_epi, RowMap row_m, const ConvBnBwd& be) {
     constexpr int NT = WM * WN * 64;
     constexpr int MI = BM / WM / 16, NI = BN / WN / 16;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -75,6 +90,86 @@ __device__ __forceinline__ void conv_epilogue(f32x4 (&acc)[BM / WM / 16][BN / WN
     constexpr int WCOLS = BN / WN;
     constexpr int SROW = WCOLS + 4;                        // padded f32 row
     constexpr int VPR = WCOLS / 8;                         // 8-column vectors per row
+    if (be.x) {
+        // (b') vector stores with a FIXED column group per lane (so it can keep running column sums):
+        //      lane -> (c8 = lane % VPR, row lane rl = lane / VPR), RPP rows of the 16-row slab per pass.
+        constexpr int RPP = (64 / VPR) < 16 ? (64 / VPR) : 16;
+        const int c8 = lane % VPR, rl = lane / VPR;
+        const bool act_lane = rl < RPP;
+        const int n0 = bn * BN + wn * WCOLS + c8 * 8;
+        const bool nval = n0 < N;                          // N % 8 == 0 (checked by the host)
+        float sc[8], sh[8], s1[8], s2[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            sc[e] = nval ? be.scale[n0 + e] : 0.f;
+            sh[e] = nval ? be.shift[n0 + e] : 0.f;
+            s1[e] = 0.f; s2[e] = 0.f;
+        }
+        const T* bx = (const T*)be.x;
+        __syncthreads();
+        float* st = lds_f + wave * (16 * SROW);
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) st[(fq * 4 + r) * SROW + j * 16 + fr] = acc[i][j][r];
+            __syncthreads();
+            if (act_lane && nval)
+                for (int row = rl; row < 16; row += RPP) {
+                    const long m = row_m(wm * (BM / WM) + i * 16 + row);
+                    if (m < 0) continue;
+                    float o[8], xv[8];
+                    const float4 lo = *(const float4*)(st + row * SROW + c8 * 8), hi = *(const float4*)(st + row * SROW + c8 * 8 + 4);
+                    o[0] = lo.x; o[1] = lo.y; o[2] = lo.z; o[3] = lo.w; o[4] = hi.x; o[5] = hi.y; o[6] = hi.z; o[7] = hi.w;
+                    if (bias) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) o[e] += bias[n0 + e];
+                    }
+                    if (residual) {
+                        float rr[8];
+                        V8<T>::ld(residual + m * g.res_ld + n0, rr);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) o[e] += rr[e];
+                    }
+                    V8<T>::st((T*)out + m * g.out_ld + n0, o);
+                    V8<T>::ld(bx + m * be.x_ld + n0, xv);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        float dpre = o[e];
+                        if (be.act == ACT_SWISH) dpre *= dswishf_(xv[e] * sc[e] + sh[e]);
+                        s1[e] += dpre;
+                        s2[e] += dpre * xv[e];
+                    }
+                }
+            __syncthreads();
+        }
+        // column sums of the tile: [WM * RPP row lanes][BN][2] through LDS, then one slab row per M-tile
+        float* red = lds_f;
+        if (act_lane) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int idx = ((wm * RPP + rl) * BN + wn * WCOLS + c8 * 8 + e) * 2;
+                red[idx] = s1[e]; red[idx + 1] = s2[e];
+            }
+        }
+        __syncthreads();
+        for (int nl = tid; nl < BN; nl += NT) {
+            const int n = bn * BN + nl;
+            if (n >= N) continue;
+            float a1 = 0.f, a2 = 0.f;
+            for (int w = 0; w < WM * RPP; ++w) { a1 += red[(w * BN + nl) * 2]; a2 += red[(w * BN + nl) * 2 + 1]; }
+            bn_store_partial(be.partials + ((long)bm * 2) * N + n, a1);
+            bn_store_partial(be.partials + ((long)bm * 2 + 1) * N + n, a2);
+        }
+        // With a counter the last M-tile of this column of tiles finalizes in place.  That makes every
+        // workgroup wait for its own output stores and an atomic round trip before it frees its LDS
+        // (measured: +4..8 us on kernels of 15-25 us), so the host normally passes no counter and runs
+        // nvae_bn_bwd_finalize_s on the slab instead.
+        if (be.fin.counter && bn_last_arriver(be.fin.counter + bn, be.m_tiles))
+            bn_fin_bwd(be.fin, be.partials, be.m_tiles, N, bn * BN, (BN + 63) / 64);
+        return;
+    }
     if (vec_epi) {
         __syncthreads();
         float* st = lds_f + wave * (16 * SROW);
@@ -159,7 +254,7 @@ __global__ __launch_bounds__(WM* WN * 64) void k_conv_gemm2(
     NvaeConvGeom g, const T* __restrict__ src, const T* __restrict__ wT, int w_ld,
     const float* __restrict__ bias, const T* residual, void* out, int out_f32, int M, int K, int n_tiles,
     int total_tiles, FastDiv fd_hw, FastDiv fd_w, const uint4* __restrict__ zeros, float* stats,
-    int vec_epi) {
+    int vec_epi, ConvBnBwd be) {
     constexpr int NT = WM * WN * 64;
     constexpr int VE = Tr<T>::VE;
     constexpr int BKE = BKC * VE;                  // K elements per ring step (BKC 16-B chunks per row)
@@ -289,7 +384,7 @@ __global__ __launch_bounds__(WM* WN * 64) void k_conv_gemm2(
     }
 
     conv_epilogue<T, BM, BN, WM, WN>(acc, (float*)lds, g, bias, residual, out, out_f32, bm, bn, stats, vec_epi,
-                                     [&](int r) -> long { int m = bm * BM + r; return m < M ? (long)m : -1L; });
+                                     [&](int r) -> long { int m = bm * BM + r; return m < M ? (long)m : -1L; }, be);
 }
 
 // =========================================================================================
@@ -309,7 +404,8 @@ template <typename T, int BN, int KS>
 __global__ __launch_bounds__(512) void k_conv_halo(
     NvaeConvGeom g, const T* __restrict__ src, const T* __restrict__ wT, int w_ld,
     const float* __restrict__ bias, const T* residual, void* out, int out_f32, int n_tiles, int total_tiles,
-    int patches_w, int patches_per_img, const uint4* __restrict__ zeros, float* stats, int vec_epi) {
+    int patches_w, int patches_per_img, const uint4* __restrict__ zeros, float* stats, int vec_epi,
+    ConvBnBwd be) {
     constexpr int BM = 256, WM = 4, WN = 2, NT = 512;
     constexpr int VE = Tr<T>::VE;
     constexpr int CCH = 8 * VE;                       // channels per halo chunk (64 bf16 / 32 f32)
@@ -421,7 +517,7 @@ __global__ __launch_bounds__(512) void k_conv_halo(
         if (++tap == TAPS) { tap = 0; ++cc; }
     }
     conv_epilogue<T, BM, BN, WM, WN>(acc, (float*)lds, g, bias, residual, out, out_f32, bp, bn, stats, vec_epi,
-                                     [&](int r) -> long { return ((long)b * H + py0 + (r >> 4)) * W + px0 + (r & 15); });
+                                     [&](int r) -> long { return ((long)b * H + py0 + (r >> 4)) * W + px0 + (r & 15); }, be);
 }
 
 // halo kernel eligibility (must agree between the launcher and nvae_conv_gemm_mtiles)
@@ -449,7 +545,9 @@ static int conv_gemm_bm(int dtype, const NvaeConvGeom* g) {
 template <typename T>
 static int launch_conv_gemm(const NvaeConvGeom* g, const void* src, const void* wT, int w_ld,
                             const float* bias, const void* residual, void* out, int out_f32,
-                            float* stats, hipStream_t s) {
+                            float* stats, hipStream_t s, const ConvBnBwd* fuse = nullptr) {
+    ConvBnBwd be{};
+    if (fuse) be = *fuse;
     const int M = g->B * g->Hout * g->Wout, K = g->KH * g->KW * g->Cin, N = g->Cout;
     FastDiv fd_hw = make_fastdiv((unsigned)(g->Hout * g->Wout)), fd_w = make_fastdiv((unsigned)g->Wout);
     const uint4* zeros = zero_page();
@@ -457,15 +555,16 @@ static int launch_conv_gemm(const NvaeConvGeom* g, const void* src, const void* 
     const int vo = out_f32 ? 4 : (int)(16 / sizeof(T));
     const int vec_epi = (g->out_ld % vo == 0) && aligned16(out) &&
                         (!residual || (g->res_ld % (int)(16 / sizeof(T)) == 0 && aligned16(residual)));
+    if (be.x && (!vec_epi || out_f32 || N % 8 != 0)) return 1;     // fusion needs the vector epilogue
     if (conv_halo_ok(sizeof(T) == 2 ? NVAE_BF16 : NVAE_F32, g)) {
         const int pw = g->Win / 16, ppi = (g->Hin / 16) * pw;
         const int mt = g->B * ppi, nt = cdiv(N, 192);
         if (g->KH == 5)
             hipLaunchKernelGGL((k_conv_halo<T, 192, 5>), mt * nt, 512, 0, s, *g, (const T*)src, (const T*)wT, w_ld, bias,
-                               (const T*)residual, out, out_f32, nt, mt * nt, pw, ppi, zeros, stats, vec_epi);
+                               (const T*)residual, out, out_f32, nt, mt * nt, pw, ppi, zeros, stats, vec_epi, be);
         else
             hipLaunchKernelGGL((k_conv_halo<T, 192, 3>), mt * nt, 512, 0, s, *g, (const T*)src, (const T*)wT, w_ld, bias,
-                               (const T*)residual, out, out_f32, nt, mt * nt, pw, ppi, zeros, stats, vec_epi);
+                               (const T*)residual, out, out_f32, nt, mt * nt, pw, ppi, zeros, stats, vec_epi, be);
         return 0;
     }
 #define LAUNCH2(BM_, BN_, WM_, WN_, ST_, BKC_)                                                          \
@@ -473,7 +572,7 @@ static int launch_conv_gemm(const NvaeConvGeom* g, const void* src, const void* 
         int mt = cdiv(M, BM_), nt = cdiv(N, BN_);                                                       \
         hipLaunchKernelGGL((k_conv_gemm2<T, BM_, BN_, WM_, WN_, ST_, BKC_>), mt * nt, WM_ * WN_ * 64, 0, s, *g, \
                            (const T*)src, (const T*)wT, w_ld, bias, (const T*)residual, out, out_f32, M, \
-                           K, nt, mt * nt, fd_hw, fd_w, zeros, stats, vec_epi);                         \
+                           K, nt, mt * nt, fd_hw, fd_w, zeros, stats, vec_epi, be);                     \
     }
     // Large problems: 128-row tiles, 8 waves; N tile with the least padding (ties -> larger).
     // Small problems (few tiles): 64 x 64 tiles, 4 waves, so that the grid covers the chip.
@@ -517,3 +616,35 @@ extern "C" int nvae_conv_gemm(int dtype, const NvaeConvGeom* g, const void* src,
     return NVAE_OK;
 }
 
+
+// nvae_conv_gemm for a data gradient whose destination feeds a BatchNorm backward: see ConvBnBwd.
+extern "C" int nvae_conv_gemm_bnbwd(int dtype, const NvaeConvGeom* g, const void* src, const void* wT, int w_ld,
+                                    const float* bias, const void* residual, void* out,
+                                    const NvaeBnBwdFuse* f, void* stream) {
+    if (int e = check_geom_mfma("conv_gemm_bnbwd", g)) return e;
+    NVAE_REQUIRE(src && wT && out && f, "conv_gemm_bnbwd: NULL pointer");
+    const int ve = (dtype == NVAE_BF16) ? 8 : 4;
+    NVAE_REQUIRE(g->Cin % ve == 0 && g->in_ld % ve == 0 && w_ld % ve == 0,
+                 "conv_gemm_bnbwd: Cin=%d in_ld=%d w_ld=%d must be multiples of %d", g->Cin, g->in_ld, w_ld, ve);
+    NVAE_REQUIRE(w_ld >= g->KH * g->KW * g->Cin, "conv_gemm_bnbwd: w_ld too small");
+    NVAE_REQUIRE(aligned16(src) && aligned16(wT), "conv_gemm_bnbwd: src/wT must be 16-B aligned");
+    NVAE_REQUIRE(!residual || g->res_ld >= g->Cout, "conv_gemm_bnbwd: res_ld too small");
+    NVAE_REQUIRE(f->x && f->scale && f->shift && f->partials, "conv_gemm_bnbwd: NULL field in NvaeBnBwdFuse");
+    NVAE_REQUIRE(!f->counters || (f->mean && f->invstd && f->dgamma && f->dbeta && f->k0k1),
+                 "conv_gemm_bnbwd: in-kernel finalize (counters) needs mean/invstd/dgamma/dbeta/k0k1");
+    NVAE_REQUIRE(g->Cout % 8 == 0 && f->x_ld % 8 == 0 && f->x_ld >= g->Cout && aligned16(f->x),
+                 "conv_gemm_bnbwd: Cout=%d / x_ld=%d must be multiples of 8 and x 16-B aligned", g->Cout, f->x_ld);
+    NVAE_REQUIRE(f->act == ACT_NONE || f->act == ACT_SWISH, "conv_gemm_bnbwd: act %d unsupported", f->act);
+    ConvBnBwd be{};
+    be.x = f->x; be.x_ld = f->x_ld; be.act = f->act; be.m_tiles = nvae_conv_gemm_mtiles(dtype, g);
+    be.scale = f->scale; be.shift = f->shift; be.partials = f->partials;
+    be.fin.counter = f->counters;
+    be.fin.inv_n = 1.0f / (float)((long)g->B * g->Hout * g->Wout);
+    be.fin.scale = (float*)f->scale; be.fin.mean = (float*)f->mean; be.fin.invstd = (float*)f->invstd;
+    be.fin.dgamma = f->dgamma; be.fin.dbeta = f->dbeta; be.fin.k0k1 = f->k0k1; be.fin.frozen = f->frozen;
+    int rc = 0;
+    DISPATCH_T(dtype, rc = launch_conv_gemm<T>(g, src, wT, w_ld, bias, residual, out, 0, nullptr, (hipStream_t)stream, &be);)
+    NVAE_REQUIRE(rc == 0, "conv_gemm_bnbwd: output rows are not 16-B aligned (out_ld=%d res_ld=%d)", g->out_ld, g->res_ld);
+    NVAE_LAUNCH_CHECK("conv_gemm_bnbwd");
+    return NVAE_OK;
+}

@@ -22,13 +22,16 @@ def same_pad(in_size: int, k: int, s: int) -> Tuple[int, int]:
 
 class Var:
     """An NHWC activation and (lazily) its gradient."""
-    __slots__ = ("t", "g", "needs_grad", "stats")
+    __slots__ = ("t", "g", "needs_grad", "stats", "uses", "bn_src")
 
     def __init__(self, t: torch.Tensor, needs_grad: bool = True):
         self.t = t
         self.g: Optional[torch.Tensor] = None
         self.needs_grad = needs_grad
         self.stats = None   # (slab [S,2,C] f32, S): BN statistics partials emitted by the producing conv
+        self.uses = 0       # ops that consumed this activation (each will add to .g in backward)
+        self.bn_src = None  # set by bn_act on its output: what a consumer's data-gradient kernel needs
+        #                     to reduce the BatchNorm backward sums in its epilogue (nvae_conv_gemm_bnbwd)
 
     @property
     def shape(self):
@@ -36,6 +39,7 @@ class Var:
 
 
 FUSED_FIN = os.environ.get("NVAE_BN_FUSED_FIN", "1") != "0"
+FUSE_BN_BWD = os.environ.get("NVAE_BN_BWD_FUSE", "1") != "0"   # BN backward sums in the dgrad epilogue
 
 
 class Ctx:
@@ -136,6 +140,7 @@ def affine(ctx: Ctx, x: torch.Tensor, a: float, b: float) -> Var:
 
 
 def unary(ctx: Ctx, x: Var, op: int) -> Var:
+    x.uses += 1
     y = Var(ctx.empty(x.t.shape), x.needs_grad)
     call("nvae_unary_fwd", ctx.dt, op, ptr(x.t), ptr(y.t), x.t.numel(), 0.0, 0.0)
     if ctx.record and x.needs_grad:
@@ -169,6 +174,9 @@ def conv2d(ctx: Ctx, x: Var, conv, *, stride: int = 1, up: int = 1, pad: Optiona
     DecoderSampleCombiner, decoder.py:115-117); out/out_coff write a channel slice of an existing
     tensor (concat-free SkipScaler, preprocess.py:65-74)."""
     ps = ctx.ps
+    x.uses += 1
+    if residual is not None:
+        residual.uses += 1
     B, H, W, Cx = x.t.shape
     k = conv.k
     cin = conv.cin if cin is None else cin
@@ -249,7 +257,24 @@ def conv2d(ctx: Ctx, x: Var, conv, *, stride: int = 1, up: int = 1, pad: Optiona
                 if cin != Cx and not acc:
                     # partial-channel write into a fresh buffer is not expected on this path
                     raise RuntimeError("conv2d backward: channel-sliced input must be accumulated")
-                if d_mfma:
+                src = x.bn_src
+                fuse = (FUSE_BN_BWD and d_mfma and src is not None and x.uses == 1 and up == 1 and not acc
+                        and cin == Cx and c_off == 0 and Cx % 8 == 0)
+                if fuse:
+                    # x = act(BN(x0)) and this conv is its only consumer: reduce the BN backward sums in
+                    # the epilogue of the data-gradient kernel (the BN closure then only applies)
+                    wD = ptr(ps.wcopies) + conv.wd_off * ps.wcopies.element_size()
+                    mt = L.load().nvae_conv_gemm_mtiles(ctx.dt, C.byref(gd))
+                    src["partials"] = ctx.empty((mt, 2, Cx), torch.float32)
+                    src["k0k1"] = ctx.empty((2, Cx), torch.float32)
+                    src["mtiles"] = mt
+                    f = L.BnBwdFuse(ptr(src["x"]), Cx, src["act"], src["frozen"], src["scale"], src["shift"],
+                                    src["mean"], src["invstd"], ptr(src["partials"]), None,
+                                    src["dgamma"], src["dbeta"], ptr(src["k0k1"]))
+                    call("nvae_conv_gemm_bnbwd", ctx.dt, C.byref(gd), dy_ptr, wD, conv.wd_ld, None, None,
+                         ptr(dst), C.byref(f))
+                    src["fused"] = True
+                elif d_mfma:
                     wD = ptr(ps.wcopies) + (conv.wd_off + c_off * conv.wd_ld) * ps.wcopies.element_size()
                     call("nvae_conv_gemm", ctx.dt, C.byref(gd), dy_ptr, wD, conv.wd_ld, None, resid,
                          ptr(dst), 0, None)
@@ -267,6 +292,7 @@ def conv2d(ctx: Ctx, x: Var, conv, *, stride: int = 1, up: int = 1, pad: Optiona
 def dwconv5(ctx: Ctx, x: Var, dw) -> Var:
     """DepthwiseConv2D((5,5), padding='same') with bias, decoder.py:130."""
     ps = ctx.ps
+    x.uses += 1
     B, H, W, Cc = x.t.shape
     y = Var(ctx.empty(x.t.shape))
     call("nvae_dwconv5", ctx.dt, ptr(x.t), ptr(ps.view(dw.w)), ptr(ps.view(dw.b)), ptr(y.t), B, H, W, Cc, 0, 0)
@@ -289,6 +315,7 @@ BN_EPS = 1e-5
 
 def bn_act(ctx: Ctx, x: Var, bn, act: int = L.ACT_NONE) -> Var:
     ps = ctx.ps
+    x.uses += 1
     B, H, W, Cc = x.t.shape
     rows = B * H * W
     coef = ctx.empty((4, Cc), torch.float32)   # scale, shift, mean, invstd
@@ -315,10 +342,22 @@ def bn_act(ctx: Ctx, x: Var, bn, act: int = L.ACT_NONE) -> Var:
     call("nvae_bn_apply", ctx.dt, ptr(x.t), ptr(y.t), rows, Cc, scale, shift, act)
     if ctx.record:
         frozen = 0 if ctx.training else 1      # tf_literal: backward through moving-statistics BN
+        dgamma = ptr(ps.grads) + bn.gamma.off * 4
+        dbeta = ptr(ps.grads) + bn.beta.off * 4
+        info = dict(x=x.t, act=act, frozen=frozen, scale=scale, shift=shift, mean=mean, invstd=invstd,
+                    dgamma=dgamma, dbeta=dbeta, fused=False, coef=coef)
+        y.bn_src = info
 
         def bwd():
-            dgamma = ptr(ps.grads) + bn.gamma.off * 4
-            dbeta = ptr(ps.grads) + bn.beta.off * 4
+            if info["fused"]:
+                # the sums were produced by the consumer's data-gradient kernel (conv2d backward)
+                call("nvae_bn_bwd_finalize_s", ptr(info["partials"]), info["mtiles"], rows, Cc, scale, mean, invstd,
+                     dgamma, dbeta, ptr(info["k0k1"]), frozen)
+                if x.needs_grad:
+                    g, acc = ctx.grad_of(x)
+                    call("nvae_bn_bwd_apply", ctx.dt, ptr(x.t), ptr(y.g), ptr(g), rows, Cc, scale, shift,
+                         ptr(info["k0k1"]), act, acc)
+                return
             part = ctx.empty((S, 2, Cc), torch.float32)
             k0k1 = ctx.empty((2, Cc), torch.float32)
             if FUSED_FIN:
@@ -343,6 +382,8 @@ def bn_act(ctx: Ctx, x: Var, bn, act: int = L.ACT_NONE) -> Var:
 def se_residual(ctx: Ctx, x: Var, se, skip: Var, skip_scale: float, branch_scale: float) -> Var:
     """y = skip_scale*skip + branch_scale*SE(x)   (SURVEY Q3 for which side carries the 0.1)."""
     ps = ctx.ps
+    x.uses += 1
+    skip.uses += 1
     B, H, W, Cc = x.t.shape
     HW, Hd = H * W, se.hidden
     pooled = ctx.empty((B, Cc), torch.float32)
@@ -362,8 +403,11 @@ def se_residual(ctx: Ctx, x: Var, se, skip: Var, skip_scale: float, branch_scale
             call("nvae_se_bwd_reduce", ctx.dt, ptr(x.t), ptr(y.g), B, HW, Cc, ptr(r))
             gp = ptr(ps.grads)
             call("nvae_se_gate_bwd", ptr(r), ptr(pooled), ptr(gate), ptr(hidden), B, HW, Cc, Hd, w1, w2,
-                 branch_scale, gp + se.w1.off * 4, gp + se.b1.off * 4, gp + se.w2.off * 4,
-                 gp + se.b2.off * 4, ptr(dpool), ptr(scratch))
+                 branch_scale, None, None, None, None, ptr(dpool), ptr(scratch))
+            # the FC parameter gradients are off the data-gradient chain: side stream, like the conv wgrads
+            ctx.side_launch(lambda: call("nvae_se_wgrad", ptr(pooled), ptr(hidden), ptr(scratch), B, HW, Cc, Hd,
+                                         gp + se.w1.off * 4, gp + se.b1.off * 4, gp + se.w2.off * 4,
+                                         gp + se.b2.off * 4), pooled, hidden, scratch)
             gx, accx = ctx.grad_of(x)
             if skip.needs_grad:
                 gs, accs = ctx.grad_of(skip)
@@ -384,6 +428,9 @@ def sampler(ctx: Ctx, enc_p: Var, dec_p: Optional[Var], eps: torch.Tensor, kl_ou
             logq: Optional[torch.Tensor] = None, logp: Optional[torch.Tensor] = None,
             mu_sigma: Optional[torch.Tensor] = None) -> Var:
     """Sampler.call + this group's KL (+ log q / log p): common.py:76-102, models.py:197-201."""
+    enc_p.uses += 1
+    if dec_p is not None:
+        dec_p.uses += 1
     B, H, W, L2 = enc_p.t.shape
     Lc = L2 // 2
     assert enc_p.t.dtype == torch.float32 and eps.dtype == torch.float32 and eps.shape == (B, H, W, Lc)
