@@ -35,3 +35,26 @@ def test_oracle_reproduces_golden_vectors():
     for k in make_golden.GRAD_KEYS:
         assert close(o["grads"][k].detach(), gold["grad/" + k], 2e-5), k
         assert close(orc.s.params[k].detach(), gold["updated/" + k]), k
+
+
+def test_oracle_reproduces_rgb_golden_vectors():
+    """The RGB / mixture-of-logistics fixture (tests/golden/nvae_rgb_small.npz, make_golden_rgb.py)."""
+    import make_golden_rgb as mg
+    from oracle.nvae_oracle import dmol_sample
+    gold = np.load(os.path.join(HERE, "golden", "nvae_rgb_small.npz"))
+    orc, x, eps, u_mix, u_pix = mg.build()
+    assert np.allclose(make_golden.checksum(orc), gold["checksum"], rtol=1e-12, atol=1e-12)
+    assert close(x.numpy(), gold["x"]) and close(u_mix.numpy(), gold["u_mix"])
+    logits, zp, lp, lq, _ = orc.call(x, eps, training=False, nll=True)
+    assert logits.shape[-1] == 10 * mg.M
+    assert close(logits.detach(), gold["inf/logits"]) and close(lp.detach(), gold["inf/log_p"])
+    assert close(orc.calculate_recon_loss(x, logits).detach(), gold["inf/recon"])
+    s_logits = orc.sample(mg.B, 0.8, eps).detach()
+    assert close(s_logits, gold["sample/logits_t0.8"])
+    assert close(dmol_sample(s_logits, mg.M, u_mix, u_pix, 1.0), gold["sample/image_t0.8"], 1e-5)
+    orc.steps = 100
+    o = orc.train_step(x, eps, decay_steps=1000)
+    for k in ("loss", "reconstruction_loss", "kl_loss", "bn_loss", "kl_per_group", "kl_coeff"):
+        assert close(o[k].detach(), gold["train/" + k]), k
+    for k in mg.GRAD_KEYS:
+        assert close(o["grads"][k].detach(), gold["grad/" + k], 2e-5), k
