@@ -218,11 +218,85 @@ __global__ __launch_bounds__(256) void k_conv_thin_wgrad(NvaeConvGeom g, const T
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// 1x1 convolutions with at most 32 input channels (the 20 latent channels of DecoderSampleCombiner,
+// decoder.py:110-117): dw[k, n] += sum_m x[m, k] * dy[m, n].  The generic thin kernel above spends its
+// time in 2-B gathers and an 88-value shuffle tree per thread; here a workgroup stages 64 rows of x
+// (all K channels) and of dy (a 64-channel strip) in LDS once and thread (kq, n4) accumulates
+// dw[kq (+16), 4 channels] over the rows: 2-3 LDS reads per 4-8 FMAs, no cross-lane reduction at all.
+// ---------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void k_conv_smallk_wgrad(const T* __restrict__ x, int in_ld, int Cin,
+                                                           const T* __restrict__ dy, int out_ld, int Cout,
+                                                           float* dw, int dw_ld, float* db, long M,
+                                                           int rows_per_block) {
+    constexpr int RT = 64;
+    __shared__ float sx[RT][33];                       // f32, padded: (row, k) reads are conflict-free
+    __shared__ __attribute__((aligned(16))) T sd[RT][64];
+    const int n_base = blockIdx.x * 64;
+    const int n4 = threadIdx.x & 15, kq = threadIdx.x >> 4;      // 4 channels, k = kq and kq + 16
+    const long r0 = (long)blockIdx.y * rows_per_block;
+    long r1 = r0 + rows_per_block;
+    if (r1 > M) r1 = M;
+    float a0[4] = {0.f, 0.f, 0.f, 0.f}, a1[4] = {0.f, 0.f, 0.f, 0.f}, ab[4] = {0.f, 0.f, 0.f, 0.f};
+    const bool k1 = kq + 16 < Cin;
+    constexpr int VE = 16 / (int)sizeof(T);
+    for (long t0 = r0; t0 < r1; t0 += RT) {
+        __syncthreads();
+        for (int q = threadIdx.x; q < RT * 32; q += 256) {       // x tile, zero-padded to 32 channels
+            const int r = q >> 5, k = q & 31;
+            sx[r][k] = (t0 + r < r1 && k < Cin) ? ldf<T>(x + (t0 + r) * in_ld + k) : 0.f;
+        }
+        for (int q = threadIdx.x; q < RT * (64 / VE); q += 256) {
+            const int r = q / (64 / VE), cc = (q - r * (64 / VE)) * VE;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (t0 + r < r1 && n_base + cc < Cout) v = *(const uint4*)(dy + (t0 + r) * out_ld + n_base + cc);
+            *(uint4*)(&sd[r][cc]) = v;
+        }
+        __syncthreads();
+#pragma unroll 8
+        for (int r = 0; r < RT; ++r) {
+            float d[4];
+            if (sizeof(T) == 2) {
+                const uint2 u = *(const uint2*)(&sd[r][n4 * 4]);
+                d[0] = __uint_as_float(u.x << 16); d[1] = __uint_as_float(u.x & 0xffff0000u);
+                d[2] = __uint_as_float(u.y << 16); d[3] = __uint_as_float(u.y & 0xffff0000u);
+            } else {
+                const float4 u = *(const float4*)(&sd[r][n4 * 4]);
+                d[0] = u.x; d[1] = u.y; d[2] = u.z; d[3] = u.w;
+            }
+            const float x0 = sx[r][kq], x1 = sx[r][kq + 16];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { a0[e] += x0 * d[e]; a1[e] += x1 * d[e]; ab[e] += d[e]; }
+        }
+    }
+    const int n = n_base + n4 * 4;
+    if (n >= Cout) return;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        if (kq < Cin) atomicAdd(dw + (long)kq * dw_ld + n + e, a0[e]);
+        if (k1) atomicAdd(dw + (long)(kq + 16) * dw_ld + n + e, a1[e]);
+        if (db && kq == 0) atomicAdd(db + n + e, ab[e]);
+    }
+}
+
 template <typename T>
 static bool launch_thin_wgrad(const NvaeConvGeom* g, const void* x, const void* dy, float* dw, int dw_ld,
                               float* db, hipStream_t s) {
     constexpr int ve = sizeof(T) == 2 ? 8 : 4;
     const long M = (long)g->B * g->Hout * g->Wout;
+    if (g->KH == 1 && g->KW == 1 && g->stride == 1 && g->div == 1 && g->Cin <= 32 && g->Cout % 8 == 0 &&
+        g->out_ld % ve == 0 && aligned16(dy) && g->Hin == g->Hout && g->Win == g->Wout) {
+        const int strips = cdiv(g->Cout, 64);
+        long S = 512 / strips;                 // ~512 workgroups, whole 64-row tiles each
+        if (S > (M + 63) / 64) S = (M + 63) / 64;
+        if (S < 1) S = 1;
+        long rpb = ((M + S - 1) / S + 63) / 64 * 64;
+        S = (M + rpb - 1) / rpb;
+        hipLaunchKernelGGL((k_conv_smallk_wgrad<T>), dim3(strips, (unsigned)S), 256, 0, s, (const T*)x, g->in_ld, g->Cin,
+                           (const T*)dy, g->out_ld, g->Cout, dw, dw_ld, db, M, (int)rpb);
+        return true;
+    }
     int variant, J, CV;
     if (g->Cout % 8 == 0 && g->out_ld % ve == 0 && aligned16(dy) && g->KH * g->KW * g->Cin <= 64) {
         variant = 0; J = g->KH * g->KW * g->Cin; CV = g->Cout;

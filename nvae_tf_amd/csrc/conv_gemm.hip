@@ -400,20 +400,20 @@ __global__ __launch_bounds__(WM* WN * 64) void k_conv_gemm2(
 //   Halo rows are [pixel][8 chunks], slot = chunk ^ (row & 7): conflict-free for the 16x16x32 operand
 //   read at ANY row offset (the tap shift moves the 16-row window by kh*20 + kw rows).
 // =========================================================================================
-template <typename T, int BN, int KS>
-__global__ __launch_bounds__(512) void k_conv_halo(
+template <typename T, int BN, int KS, int WM>
+__global__ __launch_bounds__(WM * 128) void k_conv_halo(
     NvaeConvGeom g, const T* __restrict__ src, const T* __restrict__ wT, int w_ld,
     const float* __restrict__ bias, const T* residual, void* out, int out_f32, int n_tiles, int total_tiles,
     int patches_w, int patches_per_img, const uint4* __restrict__ zeros, float* stats, int vec_epi,
     ConvBnBwd be) {
-    constexpr int BM = 256, WM = 4, WN = 2, NT = 512;
+    constexpr int BM = 256, WN = 2, NT = WM * WN * 64;
     constexpr int VE = Tr<T>::VE;
     constexpr int CCH = 8 * VE;                       // channels per halo chunk (64 bf16 / 32 f32)
     constexpr int HP = 16 + KS - 1, HROWS = HP * HP;
     constexpr int A_CHUNKS = (HROWS * 8 + 63) / 64 * 64;   // whole wave-instructions; the tail DMAs zeros
     constexpr int A_PASSES = (A_CHUNKS + NT - 1) / NT;
     constexpr int B_CHUNKS = BN * 8, BCH = B_CHUNKS / NT;
-    constexpr int MI = 4, NI = BN / WN / 16;
+    constexpr int MI = 16 / WM, NI = BN / WN / 16;    // a wave owns MI rows of the 16 x 16 patch
     constexpr int PAD = (KS - 1) / 2, TAPS = KS * KS;
     static_assert(B_CHUNKS % NT == 0 && A_PASSES <= TAPS, "tile/thread mismatch");
     __shared__ uint4 lds[2 * A_CHUNKS + 2 * B_CHUNKS];
@@ -501,7 +501,7 @@ __global__ __launch_bounds__(512) void k_conv_halo(
             uint4 af[MI], bf[NI];
 #pragma unroll
             for (int i = 0; i < MI; ++i) {
-                const int hrow = (wm * 4 + i + kh) * HP + kw + fr;
+                const int hrow = (wm * MI + i + kh) * HP + kw + fr;
                 af[i] = abuf[hrow * 8 + ((h * 4 + fq) ^ (hrow & 7))];
             }
 #pragma unroll
@@ -520,6 +520,9 @@ __global__ __launch_bounds__(512) void k_conv_halo(
                                      [&](int r) -> long { return ((long)b * H + py0 + (r >> 4)) * W + px0 + (r & 15); }, be);
 }
 
+#ifndef HALO_WM
+#define HALO_WM 4      // waves along M of the halo kernel: 4 -> 8 waves of 64 x 96, 2 -> 4 waves of 128 x 96
+#endif
 // halo kernel eligibility (must agree between the launcher and nvae_conv_gemm_mtiles)
 static bool conv_halo_ok(int dtype, const NvaeConvGeom* g) {
     const int cch = dtype == NVAE_BF16 ? 64 : 32;
@@ -560,10 +563,10 @@ static int launch_conv_gemm(const NvaeConvGeom* g, const void* src, const void* 
         const int pw = g->Win / 16, ppi = (g->Hin / 16) * pw;
         const int mt = g->B * ppi, nt = cdiv(N, 192);
         if (g->KH == 5)
-            hipLaunchKernelGGL((k_conv_halo<T, 192, 5>), mt * nt, 512, 0, s, *g, (const T*)src, (const T*)wT, w_ld, bias,
+            hipLaunchKernelGGL((k_conv_halo<T, 192, 5, HALO_WM>), mt * nt, HALO_WM * 128, 0, s, *g, (const T*)src, (const T*)wT, w_ld, bias,
                                (const T*)residual, out, out_f32, nt, mt * nt, pw, ppi, zeros, stats, vec_epi, be);
         else
-            hipLaunchKernelGGL((k_conv_halo<T, 192, 3>), mt * nt, 512, 0, s, *g, (const T*)src, (const T*)wT, w_ld, bias,
+            hipLaunchKernelGGL((k_conv_halo<T, 192, 3, 4>), mt * nt, 512, 0, s, *g, (const T*)src, (const T*)wT, w_ld, bias,
                                (const T*)residual, out, out_f32, nt, mt * nt, pw, ppi, zeros, stats, vec_epi, be);
         return 0;
     }
