@@ -280,6 +280,98 @@ __global__ __launch_bounds__(256) void k_conv_smallk_wgrad(const T* __restrict__
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// 3x3 'same' stride-1 convolutions with ONE channel on one side and <= 32 on the other: the stem
+// (Cin = 1, preprocess.py:19-23) and the logit head (Cout = 1, postprocess.py:27-30) of the MNIST model.
+// Both weight gradients are the same correlation
+//     out[t, c] += sum_pix a[pix + off(t)] * v[pix, c]        (a: 1-channel image, v: C-channel image)
+// stem: a = x, v = dy, t = tap;  head: a = dy, v = x, and the result for offset -off(t) is tap t (flip).
+// A persistent workgroup walks 16x16 tiles: the 18x18 halo of a (f32) and the 256 x 32 tile of v sit in
+// LDS, thread (pixel lane, 4 channels) keeps 9 x 4 accumulators over 8 pixels per tile and all tiles.
+// ---------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void k_conv_1ch_wgrad(const T* __restrict__ a, int a_ld, const T* __restrict__ v,
+                                                        int v_ld, int C, float* out, long out_t, long out_c,
+                                                        int flip, float* db, int db_from_a, int B, int H, int W) {
+    __shared__ float sa[18][19];
+    __shared__ __attribute__((aligned(16))) T sv[256][32];
+    __shared__ float red[4][8][41];
+    const int cg = threadIdx.x & 7, pl = threadIdx.x >> 3;
+    const int tiles_x = (W + 15) / 16, tiles_y = (H + 15) / 16;
+    const long units = (long)B * tiles_x * tiles_y;
+    float acc[9][4], sumv[4] = {0.f, 0.f, 0.f, 0.f}, suma = 0.f;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[t][e] = 0.f;
+    constexpr int VE = 16 / (int)sizeof(T);
+    for (long u = blockIdx.x; u < units; u += gridDim.x) {
+        const long b = u / (tiles_x * tiles_y);
+        const int tile = (int)(u - b * (tiles_x * tiles_y));
+        const int y0 = (tile / tiles_x) * 16, x0 = (tile % tiles_x) * 16;
+        __syncthreads();
+        for (int q = threadIdx.x; q < 18 * 18; q += 256) {
+            const int py = q / 18, px = q - py * 18;
+            const int gy = y0 - 1 + py, gx = x0 - 1 + px;
+            sa[py][px] = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? ldf<T>(a + ((b * H + gy) * (long)W + gx) * a_ld) : 0.f;
+        }
+        for (int q = threadIdx.x; q < 256 * (32 / VE); q += 256) {
+            const int pix = q / (32 / VE), cc = (q - pix * (32 / VE)) * VE;
+            const int gy = y0 + (pix >> 4), gx = x0 + (pix & 15);
+            uint4 w = make_uint4(0, 0, 0, 0);
+            if (gy < H && gx < W && cc < C) w = *(const uint4*)(v + ((b * H + gy) * (long)W + gx) * v_ld + cc);
+            *(uint4*)(&sv[pix][cc]) = w;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int pix = pl + 32 * i, py = pix >> 4, px = pix & 15;
+            float d[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) d[e] = (float)sv[pix][cg * 4 + e];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) sumv[e] += d[e];
+            suma += sa[py + 1][px + 1];
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) {
+                    const float av = sa[py + kh][px + kw];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[kh * 3 + kw][e] += av * d[e];
+                }
+        }
+    }
+    // reduce over the 32 pixel lanes: lanes with equal cg are 8 apart in a wave, then the 4 waves via LDS
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float vals[41];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) vals[t * 4 + e] = acc[t][e];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) vals[36 + e] = sumv[e];
+    vals[40] = suma;
+#pragma unroll
+    for (int j = 0; j < 41; ++j) {
+        float x = vals[j];
+        x += __shfl_xor(x, 8, 64); x += __shfl_xor(x, 16, 64); x += __shfl_xor(x, 32, 64);
+        if (lane < 8) red[wave][lane][j] = x;
+    }
+    __syncthreads();
+    for (int q = threadIdx.x; q < 8 * 41; q += 256) {
+        const int g8 = q / 41, j = q - g8 * 41;
+        const float x = red[0][g8][j] + red[1][g8][j] + red[2][g8][j] + red[3][g8][j];
+        if (j < 36) {
+            const int t = j >> 2, c = g8 * 4 + (j & 3);
+            if (c < C) atomicAdd(out + (long)(flip ? 8 - t : t) * out_t + (long)c * out_c, x);
+        } else if (db) {
+            if (!db_from_a && j < 40) { const int c = g8 * 4 + (j - 36); if (c < C) atomicAdd(db + c, x); }
+            if (db_from_a && j == 40 && g8 == 0) atomicAdd(db, x);      // every cg lane summed the same a
+        }
+    }
+}
+
 template <typename T>
 static bool launch_thin_wgrad(const NvaeConvGeom* g, const void* x, const void* dy, float* dw, int dw_ld,
                               float* db, hipStream_t s) {
@@ -295,6 +387,20 @@ static bool launch_thin_wgrad(const NvaeConvGeom* g, const void* x, const void* 
         S = (M + rpb - 1) / rpb;
         hipLaunchKernelGGL((k_conv_smallk_wgrad<T>), dim3(strips, (unsigned)S), 256, 0, s, (const T*)x, g->in_ld, g->Cin,
                            (const T*)dy, g->out_ld, g->Cout, dw, dw_ld, db, M, (int)rpb);
+        return true;
+    }
+    const bool same3 = g->KH == 3 && g->KW == 3 && g->stride == 1 && g->div == 1 && g->pad_t == 1 && g->pad_l == 1 &&
+                       g->Hin == g->Hout && g->Win == g->Wout;
+    if (same3 && g->Cin == 1 && g->Cout <= 32 && g->Cout % ve == 0 && g->out_ld % ve == 0 && aligned16(dy)) {
+        // stem: a = x (1 channel), v = dy;  dw[tap][n], db[n] = sum dy
+        hipLaunchKernelGGL((k_conv_1ch_wgrad<T>), 256, 256, 0, s, (const T*)x, g->in_ld, (const T*)dy, g->out_ld, g->Cout,
+                           dw, (long)dw_ld, 1L, 0, db, 0, g->B, g->Hout, g->Wout);
+        return true;
+    }
+    if (same3 && g->Cout == 1 && g->Cin <= 32 && g->Cin % ve == 0 && g->in_ld % ve == 0 && aligned16(x)) {
+        // logit head: a = dy (1 channel), v = x;  dw[(tap, ci)][0] with the tap mirrored, db[0] = sum dy
+        hipLaunchKernelGGL((k_conv_1ch_wgrad<T>), 256, 256, 0, s, (const T*)dy, g->out_ld, (const T*)x, g->in_ld, g->Cin,
+                           dw, (long)g->Cin * dw_ld, (long)dw_ld, 1, db, 1, g->B, g->Hout, g->Wout);
         return true;
     }
     int variant, J, CV;
