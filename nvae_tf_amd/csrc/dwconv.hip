@@ -384,13 +384,15 @@ __global__ __launch_bounds__(256) void k_dw5_wgrad(const T* __restrict__ x, cons
 // ring and thread layout as k_dw5_fwd_ring (channel pair x 2x4 block of dy pixels): per unit 48 reads
 // of the x halo + 8 of dy feed 200 packed FMAs into the thread's 25 tap-pair accumulators, which live in
 // registers across all the units the workgroup visits.
+template <int TH, int TW, int IMGS>
 __global__ __launch_bounds__(256, 2) void k_dw5_wgrad_ring(const bf16* __restrict__ x, const bf16* __restrict__ dy,
                                                            float* dw, float* db, int B, int H, int W, int C,
                                                            int tiles_x, int tiles_per_img,
                                                            const uint4* __restrict__ zeros) {
-    constexpr int TH = 8, TW = 8, NS = 2;
+    static_assert(IMGS * (TH / 2) * (TW / 4) == 8, "8 pixel lanes of 2x4 dy pixels per workgroup");
+    constexpr int NS = 2;
     constexpr int HTH = TH + 4, HTW = TW + 4;
-    constexpr int XCH = HTH * HTW * 8, DCH = TH * TW * 8;        // 16-B chunks: x halo, dy tile
+    constexpr int XCH = IMGS * HTH * HTW * 8, DCH = IMGS * TH * TW * 8;      // 16-B chunks: x halos, dy tiles
     constexpr int KX = (XCH + 255) / 256, KD = (DCH + 255) / 256;
     constexpr int STAGE = (KX + KD) * 256;
     constexpr int RED = 4 * 32 * 52 / 4;                         // reduction buffer in uint4
@@ -400,37 +402,45 @@ __global__ __launch_bounds__(256, 2) void k_dw5_wgrad_ring(const bf16* __restric
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int c_base = blockIdx.x * DW_CC;
     const int cp = tid & 31, pl = tid >> 5;
-    const int cb = pl & 1, rb = pl >> 1;
+    constexpr int CB = TW / 4, RB = TH / 2;
+    const int cb = pl % CB, rb = (pl / CB) % RB, img = pl / (CB * RB);
     dw_f2 acc[25];
 #pragma unroll
     for (int t = 0; t < 25; ++t) acc[t] = dw_f2{0.f, 0.f};
     dw_f2 ab = {0.f, 0.f};
-    const long units = (long)B * tiles_per_img;
+    const long units = IMGS == 1 ? (long)B * tiles_per_img : (long)(B + IMGS - 1) / IMGS;
     const int nmine = blockIdx.y < units ? (int)((units - blockIdx.y + gridDim.y - 1) / gridDim.y) : 0;
     auto issue = [&](int i) {
         const long u = blockIdx.y + (long)i * gridDim.y;
-        const long b = u / tiles_per_img;
-        const int tile = (int)(u - b * tiles_per_img);
-        const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+        long b; int ty, tx;
+        if (IMGS == 1) {
+            b = u / tiles_per_img;
+            const int tile = (int)(u - b * tiles_per_img);
+            ty = tile / tiles_x; tx = tile - ty * tiles_x;
+        } else {
+            b = u * IMGS; ty = 0; tx = 0;
+        }
         const unsigned dst = lds_base + (unsigned)((i % NS) * STAGE) * 16u;
 #pragma unroll
         for (int k = 0; k < KX; ++k) {
             const int q = (k * 4 + wave) * 64 + lane;
             const int pix = q >> 3, cc = (q & 7) * 8;
-            const int py = pix / HTW, px = pix - py * HTW;
+            const int im = pix / (HTH * HTW), pi = pix - im * (HTH * HTW);
+            const int py = pi / HTW, px = pi - py * HTW;
             const int gy = ty * TH - 2 + py, gx = tx * TW - 2 + px;
-            const bool ok = q < XCH && gy >= 0 && gy < H && gx >= 0 && gx < W && c_base + cc < C;
-            const void* p = ok ? (const void*)(x + (((b * H + gy) * (long)W + gx) * C + c_base + cc)) : (const void*)zeros;
+            const bool ok = q < XCH && b + im < B && gy >= 0 && gy < H && gx >= 0 && gx < W && c_base + cc < C;
+            const void* p = ok ? (const void*)(x + ((((b + im) * H + gy) * (long)W + gx) * C + c_base + cc)) : (const void*)zeros;
             glds16(p, dst + (unsigned)((k * 4 + wave) * 64) * 16u);
         }
 #pragma unroll
         for (int k = 0; k < KD; ++k) {
             const int q = (k * 4 + wave) * 64 + lane;
             const int pix = q >> 3, cc = (q & 7) * 8;
-            const int py = pix / TW, px = pix - py * TW;
+            const int im = pix / (TH * TW), pi = pix - im * (TH * TW);
+            const int py = pi / TW, px = pi - py * TW;
             const int gy = ty * TH + py, gx = tx * TW + px;
-            const bool ok = q < DCH && gy < H && gx < W && c_base + cc < C;
-            const void* p = ok ? (const void*)(dy + (((b * H + gy) * (long)W + gx) * C + c_base + cc)) : (const void*)zeros;
+            const bool ok = q < DCH && b + im < B && gy < H && gx < W && c_base + cc < C;
+            const void* p = ok ? (const void*)(dy + ((((b + im) * H + gy) * (long)W + gx) * C + c_base + cc)) : (const void*)zeros;
             glds16(p, dst + (unsigned)(KX * 256 + (k * 4 + wave) * 64) * 16u);
         }
     };
@@ -439,8 +449,8 @@ __global__ __launch_bounds__(256, 2) void k_dw5_wgrad_ring(const bf16* __restric
         wait_vmcnt<0>();
         __syncthreads();
         if (i + 1 < nmine) issue(i + 1);
-        const bf16* sx = (const bf16*)(lds + (i % NS) * STAGE);
-        const bf16* sd = sx + KX * 256 * 8;
+        const bf16* sx = (const bf16*)(lds + (i % NS) * STAGE) + (long)img * HTH * HTW * DW_CC;
+        const bf16* sd = (const bf16*)(lds + (i % NS) * STAGE) + KX * 256 * 8 + (long)img * TH * TW * DW_CC;
         dw_f2 g[2][4];
 #pragma unroll
         for (int r = 0; r < 2; ++r)
@@ -515,7 +525,18 @@ extern "C" int nvae_dwconv5_wgrad(int dtype, const void* x, const void* dy, floa
     NVAE_REQUIRE(chunks <= 65535, "dwconv5_wgrad: too many tiles");
     dim3 grid(strips, (unsigned)chunks);
     if (dtype == NVAE_BF16 && !small) {
-        hipLaunchKernelGGL(k_dw5_wgrad_ring, grid, 256, 0, (hipStream_t)stream, (const bf16*)x, (const bf16*)dy, dw, db, B, H, W, C, tx, tx * ty, zero_page());
+        hipLaunchKernelGGL((k_dw5_wgrad_ring<8, 8, 1>), grid, 256, 0, (hipStream_t)stream, (const bf16*)x, (const bf16*)dy, dw, db, B, H, W, C, tx, tx * ty, zero_page());
+        NVAE_LAUNCH_CHECK("dwconv5_wgrad");
+        return NVAE_OK;
+    }
+    if (dtype == NVAE_BF16) {            // 4x4 tower: units of four images
+        const long u4 = (B + 3) / 4;
+        long w4 = u4 / 4;
+        if (w4 > 1024 / strips) w4 = 1024 / strips;
+        if (w4 < cdiv(256, strips)) w4 = cdiv(256, strips);
+        if (w4 > u4) w4 = u4;
+        if (w4 < 1) w4 = 1;
+        hipLaunchKernelGGL((k_dw5_wgrad_ring<4, 4, 4>), dim3(strips, (unsigned)w4), 256, 0, (hipStream_t)stream, (const bf16*)x, (const bf16*)dy, dw, db, B, H, W, C, 1, 1, zero_page());
         NVAE_LAUNCH_CHECK("dwconv5_wgrad");
         return NVAE_OK;
     }
