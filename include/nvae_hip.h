@@ -115,6 +115,12 @@ int nvae_colsum(int dtype, const void* x, long rows, int C, int ld, float* out, 
  *      flip=1 gives the data gradient.                                                         */
 int nvae_dwconv5(int dtype, const void* x, const float* w, const float* bias, void* y, int B, int H,
                  int W, int C, int flip, int accumulate, void* stream);
+/* forward pass that also emits the BatchNorm statistics of its output (decoder.py:130-131: the
+ * depthwise conv feeds BN3): stats[rows][2][C], rows = nvae_dwconv5_stats_rows(...) (0 = unsupported for
+ * this dtype: use nvae_bn_stats), consumed by nvae_bn_finalize_s.                                  */
+int nvae_dwconv5_stats_rows(int dtype, int B, int H, int W, int C);
+int nvae_dwconv5_stats(int dtype, const void* x, const float* w, const float* bias, void* y, int B, int H,
+                       int W, int C, float* stats, void* stream);
 int nvae_dwconv5_wgrad(int dtype, const void* x, const void* dy, float* dw, float* db, int B, int H,
                        int W, int C, void* stream);
 

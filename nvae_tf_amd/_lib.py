@@ -55,7 +55,9 @@ _SIGS = {
     "nvae_colsum": [_i, _p, _l, _i, _i, _p],
     "nvae_dwconv5": [_i, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i],
     "nvae_dwconv5_wgrad": [_i, _p, _p, _p, _p, _i, _i, _i, _i],
+    "nvae_dwconv5_stats": [_i, _p, _p, _p, _p, _i, _i, _i, _i, _p],
     "nvae_reduce_splits": None,
+    "nvae_dwconv5_stats_rows": None,
     "nvae_bn_stats": [_i, _p, _l, _i, _p],
     "nvae_bn_finalize": [_p, _l, _i, _p, _p, _p, _p, _f, _f, _p, _p, _p, _p],
     "nvae_bn_finalize_s": [_p, _i, _l, _i, _p, _p, _p, _p, _f, _f, _p, _p, _p, _p],
@@ -115,6 +117,8 @@ def load():
     lib.nvae_abi_version.restype = C.c_int
     lib.nvae_reduce_splits.restype = C.c_int
     lib.nvae_reduce_splits.argtypes = [_l, _i]
+    lib.nvae_dwconv5_stats_rows.restype = C.c_int
+    lib.nvae_dwconv5_stats_rows.argtypes = [_i, _i, _i, _i, _i]
     lib.nvae_conv_gemm_mtiles.restype = C.c_int
     lib.nvae_conv_gemm_mtiles.argtypes = [_i, _G]
     lib.nvae_conv_wgrad_scratch.restype = C.c_long

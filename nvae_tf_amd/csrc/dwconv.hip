@@ -146,7 +146,8 @@ template <int TH, int TW, int IMGS>
 __global__ __launch_bounds__(256, 2) void k_dw5_fwd_ring(const bf16* __restrict__ x, const float* __restrict__ w,
                                                       const float* __restrict__ bias, bf16* y, int B, int H,
                                                       int W, int C, int tiles_x, int tiles_per_img, int flip,
-                                                      int acc, const uint4* __restrict__ zeros) {
+                                                      int acc, const uint4* __restrict__ zeros,
+                                                      float* __restrict__ stats) {
     static_assert(IMGS * (TH / 2) * (TW / 4) == 8, "8 pixel lanes of 2x4 outputs per workgroup");
     constexpr int NS = 2;
     constexpr int HTH = TH + 4, HTW = TW + 4, NCH = IMGS * HTH * HTW * 8;     // 16-B chunks per unit
@@ -202,6 +203,7 @@ __global__ __launch_bounds__(256, 2) void k_dw5_fwd_ring(const bf16* __restrict_
     // pixel lane -> (image within the unit, 2-row block, 4-column block)
     constexpr int CB = TW / 4, RB = TH / 2;
     const int cb = pl % CB, rb = (pl / CB) % RB, img = pl / (CB * RB);
+    dw_f2 st1 = {0.f, 0.f}, st2 = {0.f, 0.f};       // BatchNorm statistics of this thread's outputs (stats != NULL)
     for (int i = 0; i < nmine; ++i) {
         wait_vmcnt<0>();             // this wave's part of unit i has landed (and its older y stores)
         __syncthreads();             // everyone's part is in LDS; everyone finished reading stage (i+1) % 2
@@ -243,31 +245,69 @@ __global__ __launch_bounds__(256, 2) void k_dw5_fwd_ring(const bf16* __restrict_
             for (int r = 0; r < 2; ++r)
 #pragma unroll
                 for (int p = 0; p < 4; ++p)
-                    if (gy0 + r < H && gx0 + p < W)
+                    if (gy0 + r < H && gx0 + p < W) {
                         *(unsigned*)(y + (((b * H + gy0 + r) * (long)W + gx0 + p) * C + c)) =
                             (unsigned)f2bf(o[r][p].x) | ((unsigned)f2bf(o[r][p].y) << 16);
+                        st1 += o[r][p];
+                        st2 += o[r][p] * o[r][p];
+                    }
+        }
+    }
+    if (stats) {
+        // per-workgroup column sums -> stats[blockIdx.y][2][C] (the slab nvae_bn_finalize_s consumes)
+        st1.x += __shfl_xor(st1.x, 32, 64); st1.y += __shfl_xor(st1.y, 32, 64);
+        st2.x += __shfl_xor(st2.x, 32, 64); st2.y += __shfl_xor(st2.y, 32, 64);
+        __syncthreads();                 // the ring is dead: reuse it as [4 waves][32 pairs][4]
+        float* red = (float*)lds;
+        if (lane < 32) {
+            float* r = red + (wave * 32 + lane) * 4;
+            r[0] = st1.x; r[1] = st1.y; r[2] = st2.x; r[3] = st2.y;
+        }
+        __syncthreads();
+        if (tid < 64) {
+            const int pr = tid >> 1, e = tid & 1;
+            const int cc = c_base + pr * 2 + e;
+            if (cc < C) {
+                float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+                for (int wv = 0; wv < 4; ++wv) { a1 += red[(wv * 32 + pr) * 4 + e]; a2 += red[(wv * 32 + pr) * 4 + 2 + e]; }
+                stats[((long)blockIdx.y * 2) * C + cc] = a1;
+                stats[((long)blockIdx.y * 2 + 1) * C + cc] = a2;
+            }
         }
     }
 }
 
-extern "C" int nvae_dwconv5(int dtype, const void* x, const float* w, const float* bias, void* y, int B,
-                            int H, int W, int C, int flip, int accumulate, void* stream) {
+// persistent workgroups per channel strip of the bf16 ring kernel (= rows of its statistics slab)
+static long dw_ring_rows(int B, int H, int W, int C) {
+    const bool small = H <= 4 && W <= 4;
+    const long units = small ? (B + 3) / 4 : (long)B * cdiv(W, 8) * cdiv(H, 8);
+    long nb = 1024 / cdiv(C, DW_CC);     // 4 persistent workgroups per CU in flight
+    if (nb < 1) nb = 1;
+    if (nb > units) nb = units;
+    return nb;
+}
+
+extern "C" int nvae_dwconv5_stats_rows(int dtype, int B, int H, int W, int C) {
+    if (dtype != NVAE_BF16 || B <= 0 || H <= 0 || W <= 0 || C < 8 || C % 8) return 0;
+    return (int)dw_ring_rows(B, H, W, C);
+}
+
+static int dwconv5_impl(int dtype, const void* x, const float* w, const float* bias, void* y, int B, int H, int W,
+                        int C, int flip, int accumulate, float* stats, void* stream) {
     NVAE_REQUIRE(B > 0 && H > 0 && W > 0 && C >= 8 && C % 8 == 0, "dwconv5: bad shape");
     NVAE_REQUIRE(aligned16(x) && aligned16(y) && aligned16(w) && (!bias || aligned16(bias)), "dwconv5: alignment");
+    NVAE_REQUIRE(!stats || (dtype == NVAE_BF16 && !flip && !accumulate), "dwconv5: statistics only from the bf16 forward");
     const int strips = cdiv(C, DW_CC);
     NVAE_REQUIRE(B <= 65535, "dwconv5: batch too large for the grid");
     if (dtype == NVAE_BF16) {
         const bool small = H <= 4 && W <= 4;
         const int tx = small ? 1 : cdiv(W, 8), ty = small ? 1 : cdiv(H, 8);
-        const long units = small ? (B + 3) / 4 : (long)B * tx * ty;
-        long nb = 1024 / strips;         // 4 persistent workgroups per CU in flight
-        if (nb < 1) nb = 1;
-        if (nb > units) nb = units;
-        dim3 grid(strips, (unsigned)nb);
+        dim3 grid(strips, (unsigned)dw_ring_rows(B, H, W, C));
         if (small)
-            hipLaunchKernelGGL((k_dw5_fwd_ring<4, 4, 4>), grid, 256, 0, (hipStream_t)stream, (const bf16*)x, w, bias, (bf16*)y, B, H, W, C, tx, tx * ty, flip, accumulate, zero_page());
+            hipLaunchKernelGGL((k_dw5_fwd_ring<4, 4, 4>), grid, 256, 0, (hipStream_t)stream, (const bf16*)x, w, bias, (bf16*)y, B, H, W, C, tx, tx * ty, flip, accumulate, zero_page(), stats);
         else
-            hipLaunchKernelGGL((k_dw5_fwd_ring<8, 8, 1>), grid, 256, 0, (hipStream_t)stream, (const bf16*)x, w, bias, (bf16*)y, B, H, W, C, tx, tx * ty, flip, accumulate, zero_page());
+            hipLaunchKernelGGL((k_dw5_fwd_ring<8, 8, 1>), grid, 256, 0, (hipStream_t)stream, (const bf16*)x, w, bias, (bf16*)y, B, H, W, C, tx, tx * ty, flip, accumulate, zero_page(), stats);
         NVAE_LAUNCH_CHECK("dwconv5");
         return NVAE_OK;
     }
@@ -282,6 +322,20 @@ extern "C" int nvae_dwconv5(int dtype, const void* x, const float* w, const floa
     }
     NVAE_LAUNCH_CHECK("dwconv5");
     return NVAE_OK;
+}
+
+extern "C" int nvae_dwconv5(int dtype, const void* x, const float* w, const float* bias, void* y, int B,
+                            int H, int W, int C, int flip, int accumulate, void* stream) {
+    return dwconv5_impl(dtype, x, w, bias, y, B, H, W, C, flip, accumulate, nullptr, stream);
+}
+
+// Forward pass that also emits the BatchNorm statistics of its output: stats[rows][2][C] with
+// rows = nvae_dwconv5_stats_rows(...) > 0 (per-workgroup column sums and sums of squares, taken from the
+// f32 accumulators), to be consumed by nvae_bn_finalize_s.
+extern "C" int nvae_dwconv5_stats(int dtype, const void* x, const float* w, const float* bias, void* y, int B,
+                                  int H, int W, int C, float* stats, void* stream) {
+    NVAE_REQUIRE(stats, "dwconv5_stats: NULL statistics slab");
+    return dwconv5_impl(dtype, x, w, bias, y, B, H, W, C, 0, 0, stats, stream);
 }
 
 // dw[kh,kw,c] += sum_{b,h,w} x[b,h+kh-2,w+kw-2,c] * dy[b,h,w,c];  db[c] += sum dy.

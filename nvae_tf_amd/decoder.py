@@ -42,7 +42,7 @@ class GenerativeResidualCell:
         x = ops.bn_act(ctx, inputs, self.batch_norm1)
         x = ops.conv2d(ctx, x, self.conv1, want_stats=True)
         x = ops.bn_act(ctx, x, self.batch_norm2, L.ACT_SWISH)
-        x = ops.dwconv5(ctx, x, self.depth_conv)
+        x = ops.dwconv5(ctx, x, self.depth_conv, want_stats=True)   # feeds bn3
         x = ops.bn_act(ctx, x, self.batch_norm3, L.ACT_SWISH)
         x = ops.conv2d(ctx, x, self.conv2, want_stats=True)
         x = ops.bn_act(ctx, x, self.batch_norm4)

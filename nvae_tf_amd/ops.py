@@ -289,13 +289,21 @@ def conv2d(ctx: Ctx, x: Var, conv, *, stride: int = 1, up: int = 1, pad: Optiona
     return out
 
 
-def dwconv5(ctx: Ctx, x: Var, dw) -> Var:
-    """DepthwiseConv2D((5,5), padding='same') with bias, decoder.py:130."""
+def dwconv5(ctx: Ctx, x: Var, dw, want_stats: bool = False) -> Var:
+    """DepthwiseConv2D((5,5), padding='same') with bias, decoder.py:130.  want_stats: the output feeds a
+    BatchNorm, let the kernel emit its statistics slab (bf16 path)."""
     ps = ctx.ps
     x.uses += 1
     B, H, W, Cc = x.t.shape
     y = Var(ctx.empty(x.t.shape))
-    call("nvae_dwconv5", ctx.dt, ptr(x.t), ptr(ps.view(dw.w)), ptr(ps.view(dw.b)), ptr(y.t), B, H, W, Cc, 0, 0)
+    rows = L.load().nvae_dwconv5_stats_rows(ctx.dt, B, H, W, Cc) if (want_stats and ctx.training) else 0
+    if rows > 0:
+        slab = ctx.empty((rows, 2, Cc), torch.float32)
+        call("nvae_dwconv5_stats", ctx.dt, ptr(x.t), ptr(ps.view(dw.w)), ptr(ps.view(dw.b)), ptr(y.t), B, H, W, Cc,
+             ptr(slab))
+        y.stats = (slab, rows)
+    else:
+        call("nvae_dwconv5", ctx.dt, ptr(x.t), ptr(ps.view(dw.w)), ptr(ps.view(dw.b)), ptr(y.t), B, H, W, Cc, 0, 0)
     if ctx.record:
         def bwd():
             ctx.side_launch(lambda: call("nvae_dwconv5_wgrad", ctx.dt, ptr(x.t), ptr(y.g), ptr(ps.grads) + dw.w.off * 4,

@@ -335,8 +335,19 @@ def test_dwconv5(lib, dev, dtype, B, H, W_, C_):
     tol = TOL[dtype]
     assert rel_err(y.t, y_ref) < tol and rel_err(xv.g, gr[0]) < tol
     assert rel_err(ps.get_grad("dw.w"), gr[1]) < tol and rel_err(ps.get_grad("dw.b"), gr[2]) < tol
-    # accumulate into an existing data gradient (flip = 1, accumulate = 1)
     from nvae_tf_amd._lib import call, ptr
+    # forward with fused BatchNorm statistics (bf16 ring kernel): column sums / sums of squares of the output
+    rows = lib.nvae_dwconv5_stats_rows(ctx.dt, B, H, W_, C_)
+    assert (rows > 0) == (dtype == torch.bfloat16)
+    if rows:
+        slab = torch.full((rows, 2, C_), float("nan"), device=dev)
+        y2 = torch.empty_like(y.t)
+        call("nvae_dwconv5_stats", ctx.dt, ptr(xv.t), ptr(ps.view(dw.w)), ptr(ps.view(dw.b)), ptr(y2), B, H, W_, C_,
+             ptr(slab))
+        assert torch.equal(y2, y.t)
+        yr = y_ref.detach().reshape(-1, C_)
+        assert rel_err(slab[:, 0].sum(0), yr.sum(0)) < 1e-4 and rel_err(slab[:, 1].sum(0), (yr * yr).sum(0)) < 1e-4
+    # accumulate into an existing data gradient (flip = 1, accumulate = 1)
     acc = xv.g.clone()
     call("nvae_dwconv5", ctx.dt, ptr(y.g), ptr(ps.view(dw.w)), None, ptr(acc), B, H, W_, C_, 1, 1)
     assert rel_err(acc, 2 * gr[0]) < 2 * tol
