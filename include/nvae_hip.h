@@ -185,6 +185,10 @@ int nvae_se_gate(const float* pooled_sum, int B, int HW, int C, int Hd, const fl
                  void* stream);
 int nvae_se_apply(int dtype, const void* x, const void* skip, void* y, int B, int HW, int C,
                   const float* gate, float skip_scale, float branch_scale, void* stream);
+/* nvae_se_apply that also emits the BatchNorm statistics of y (the next residual cell starts with a
+ * BatchNorm): stats[nvae_reduce_splits(B*HW, C)][2][C], consumed by nvae_bn_finalize_s.            */
+int nvae_se_apply_stats(int dtype, const void* x, const void* skip, void* y, int B, int HW, int C,
+                        const float* gate, float skip_scale, float branch_scale, float* stats, void* stream);
 int nvae_se_bwd_reduce(int dtype, const void* x, const void* dy, int B, int HW, int C,
                        float* r /*[B,C]*/, void* stream);
 int nvae_se_gate_bwd(const float* r, const float* pooled_sum, const float* gate, const float* hidden,

@@ -477,6 +477,85 @@ extern "C" int nvae_se_apply(int dtype, const void* x, const void* skip, void* y
     return NVAE_OK;
 }
 
+// SE gate + residual that also emits the BatchNorm statistics of its output (the next residual cell
+// starts with BN): strip-reduce structure (a workgroup owns <= 64 channels x a row range), y is written
+// and its column sums / sums of squares (from the f32 values) go to stats[blockIdx.y][2][C].
+template <typename T>
+__global__ __launch_bounds__(RED_THREADS) void k_se_apply_stats(const T* __restrict__ x, const T* __restrict__ skip,
+                                                               T* __restrict__ y, long rows, int C, int HW,
+                                                               int rows_per_block, const float* __restrict__ gate,
+                                                               float ss, float bs, float* __restrict__ stats) {
+    const int TGS = C >= 64 ? 8 : (C > 16 ? (C > 32 ? 8 : 4) : (C > 8 ? 2 : 1));
+    const int RL = RED_THREADS / TGS;
+    const int tg = threadIdx.x % TGS, rl = threadIdx.x / TGS;
+    const int c0 = blockIdx.x * 64 + tg * 8;
+    const bool cval = c0 < C;
+    const long r0 = (long)blockIdx.y * rows_per_block;
+    long r1 = r0 + rows_per_block;
+    if (r1 > rows) r1 = rows;
+    float acc[2][8];
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[q][j] = 0.f;
+    if (cval) {
+        for (long r = r0 + rl; r < r1; r += RL) {
+            const long off = r * (long)C + c0;
+            float v[8], k[8], g[8];
+            V8<T>::ld(x + off, v);
+            V8<T>::ld(skip + off, k);
+            ld8f(gate + (r / HW) * C + c0, g);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                v[j] = ss * k[j] + bs * v[j] * g[j];
+                acc[0][j] += v[j]; acc[1][j] += v[j] * v[j];
+            }
+            V8<T>::st(y + off, v);
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float v = acc[q][j];
+            for (int o = 32; o >= TGS; o >>= 1) v += __shfl_xor(v, o, 64);
+            acc[q][j] = v;
+        }
+    __shared__ float sm[4][8][16];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane < TGS) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) sm[wave][lane][q * 8 + j] = acc[q][j];
+    }
+    __syncthreads();
+    if (threadIdx.x < TGS && cval) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                stats[((long)blockIdx.y * 2 + q) * C + c0 + j] =
+                    sm[0][tg][q * 8 + j] + sm[1][tg][q * 8 + j] + sm[2][tg][q * 8 + j] + sm[3][tg][q * 8 + j];
+    }
+}
+
+// stats: [nvae_reduce_splits(B*HW, C)][2][C] floats, consumed by nvae_bn_finalize_s
+extern "C" int nvae_se_apply_stats(int dtype, const void* x, const void* skip, void* y, int B, int HW, int C,
+                                   const float* gate, float skip_scale, float branch_scale, float* stats,
+                                   void* stream) {
+    if (int e = check_c("se_apply_stats", C)) return e;
+    NVAE_REQUIRE(B > 0 && HW > 0 && aligned16(x) && aligned16(skip) && aligned16(y) && aligned16(gate) && stats,
+                 "se_apply_stats: bad shape/alignment");
+    const long rows = (long)B * HW;
+    const int S = nvae_reduce_splits(rows, C);
+    const long rpb = (rows + S - 1) / S;
+    dim3 grid((C + 63) / 64, S);
+    DISPATCH_T(dtype, hipLaunchKernelGGL((k_se_apply_stats<T>), grid, RED_THREADS, 0, (hipStream_t)stream, (const T*)x, (const T*)skip, (T*)y, rows, C, HW, (int)rpb, gate, skip_scale, branch_scale, stats);)
+    NVAE_LAUNCH_CHECK("se_apply_stats");
+    return NVAE_OK;
+}
+
 // Stage 1, one block per image, no atomics: dpre2[b,c] = bs*r*g*(1-g); dpre1[b,h]; dpool[b,c].
 __global__ void k_se_gate_bwd(const float* __restrict__ r, const float* __restrict__ gate,
                               const float* __restrict__ hidden, float inv_hw, int C, int Hd,

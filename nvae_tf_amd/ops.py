@@ -39,6 +39,7 @@ class Var:
 
 
 FUSED_FIN = os.environ.get("NVAE_BN_FUSED_FIN", "1") != "0"
+SE_STATS = os.environ.get("NVAE_SE_STATS", "1") != "0"         # BN statistics out of the SE + residual kernel
 FUSE_BN_BWD = os.environ.get("NVAE_BN_BWD_FUSE", "1") != "0"   # BN backward sums in the dgrad epilogue
 
 
@@ -401,8 +402,16 @@ def se_residual(ctx: Ctx, x: Var, se, skip: Var, skip_scale: float, branch_scale
     call("nvae_se_pool", ctx.dt, ptr(x.t), B, HW, Cc, ptr(pooled))
     call("nvae_se_gate", ptr(pooled), B, HW, Cc, Hd, w1, b1, w2, b2, ptr(gate), ptr(hidden))
     y = Var(ctx.empty(x.t.shape))
-    call("nvae_se_apply", ctx.dt, ptr(x.t), ptr(skip.t), ptr(y.t), B, HW, Cc, ptr(gate), skip_scale,
-         branch_scale)
+    if ctx.training and SE_STATS:
+        # the consumer is almost always the next cell's BatchNorm: emit its statistics slab here
+        S = L.load().nvae_reduce_splits(B * HW, Cc)
+        slab = ctx.empty((S, 2, Cc), torch.float32)
+        call("nvae_se_apply_stats", ctx.dt, ptr(x.t), ptr(skip.t), ptr(y.t), B, HW, Cc, ptr(gate), skip_scale,
+             branch_scale, ptr(slab))
+        y.stats = (slab, S)
+    else:
+        call("nvae_se_apply", ctx.dt, ptr(x.t), ptr(skip.t), ptr(y.t), B, HW, Cc, ptr(gate), skip_scale,
+             branch_scale)
     if ctx.record:
         def bwd():
             r = ctx.empty((B, Cc), torch.float32)
