@@ -195,6 +195,13 @@ int nvae_se_gate_bwd(const float* r, const float* pooled_sum, const float* gate,
                      int B, int HW, int C, int Hd, const float* w1, const float* w2, float branch_scale,
                      float* dw1, float* db1, float* dw2, float* db2, float* dpool,
                      float* scratch /*[B*(C+Hd)]*/, void* stream);
+/* nvae_se_bwd_apply (without accumulation into dx) when x was the output of y = act(BN(xb)) with no other
+ * consumer (decoder.py:135-146, postprocess.py:107-108): also reduces the BatchNorm-backward sums of that
+ * layer, partials[nvae_reduce_splits(B*HW, C)][2][C], for nvae_bn_bwd_finalize_s.                  */
+int nvae_se_bwd_apply_bn(int dtype, const void* dy, const float* gate, const float* dpool, void* dx,
+                         void* dskip, int B, int HW, int C, float skip_scale, float branch_scale,
+                         int acc_dskip, const void* xb, const float* scale, const float* shift, int act,
+                         float* partials, void* stream);
 /* dw1 == NULL above skips the FC parameter gradients; nvae_se_wgrad computes them later from the same
  * scratch (they do not feed the data-gradient chain: the host enqueues them on its side stream).   */
 int nvae_se_wgrad(const float* pooled_sum, const float* hidden, const float* scratch, int B, int HW,

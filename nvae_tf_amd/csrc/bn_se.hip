@@ -690,3 +690,96 @@ extern "C" int nvae_se_bwd_apply(int dtype, const void* dy, const float* gate, c
     NVAE_LAUNCH_CHECK("se_bwd_apply");
     return NVAE_OK;
 }
+
+// nvae_se_bwd_apply for the case where x (the SE input) is the output of a BatchNorm and has no other
+// consumer: dx is final here, so the BatchNorm-backward sums (sum dpre, sum dpre*xb with
+// dpre = dx * act'(scale*xb + shift), xb = the BatchNorm's input) are reduced in the same pass and written
+// as partials[S][2][C] (S = nvae_reduce_splits(B*HW, C)) for nvae_bn_bwd_finalize_s.
+template <typename T>
+__global__ __launch_bounds__(RED_THREADS) void k_se_bwd_apply_bn(
+    const T* __restrict__ dy, const float* __restrict__ gate, const float* __restrict__ dpool, T* __restrict__ dx,
+    T* dskip, long rows, int C, int HW, int rows_per_block, float ss, float bs, int acc_dskip,
+    const T* __restrict__ xb, const float* __restrict__ scale, const float* __restrict__ shift, int act,
+    float* __restrict__ partials) {
+    const int TGS = C >= 64 ? 8 : (C > 16 ? (C > 32 ? 8 : 4) : (C > 8 ? 2 : 1));
+    const int RL = RED_THREADS / TGS;
+    const int tg = threadIdx.x % TGS, rl = threadIdx.x / TGS;
+    const int c0 = blockIdx.x * 64 + tg * 8;
+    const bool cval = c0 < C;
+    const long r0 = (long)blockIdx.y * rows_per_block;
+    long r1 = r0 + rows_per_block;
+    if (r1 > rows) r1 = rows;
+    float acc[2][8], sc[8], sh[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        acc[0][j] = 0.f; acc[1][j] = 0.f;
+        sc[j] = cval ? scale[c0 + j] : 0.f;
+        sh[j] = cval ? shift[c0 + j] : 0.f;
+    }
+    if (cval) {
+        for (long r = r0 + rl; r < r1; r += RL) {
+            const long off = r * (long)C + c0;
+            const long b = r / HW;
+            float g[8], o[8], k[8], gt[8], dp[8], xv[8];
+            V8<T>::ld(dy + off, g);
+            ld8f(gate + b * C + c0, gt);
+            ld8f(dpool + b * C + c0, dp);
+            V8<T>::ld(xb + off, xv);
+            if (dskip && acc_dskip) V8<T>::ld(dskip + off, k);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                o[j] = bs * g[j] * gt[j] + dp[j];
+                k[j] = ((dskip && acc_dskip) ? k[j] : 0.f) + ss * g[j];
+                float dpre = o[j];
+                if (act == ACT_SWISH) dpre *= dswishf_(xv[j] * sc[j] + sh[j]);
+                acc[0][j] += dpre;
+                acc[1][j] += dpre * xv[j];
+            }
+            V8<T>::st(dx + off, o);
+            if (dskip) V8<T>::st(dskip + off, k);
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float v = acc[q][j];
+            for (int o = 32; o >= TGS; o >>= 1) v += __shfl_xor(v, o, 64);
+            acc[q][j] = v;
+        }
+    __shared__ float sm[4][8][16];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane < TGS) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) sm[wave][lane][q * 8 + j] = acc[q][j];
+    }
+    __syncthreads();
+    if (threadIdx.x < TGS && cval) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                partials[((long)blockIdx.y * 2 + q) * C + c0 + j] =
+                    sm[0][tg][q * 8 + j] + sm[1][tg][q * 8 + j] + sm[2][tg][q * 8 + j] + sm[3][tg][q * 8 + j];
+    }
+}
+
+extern "C" int nvae_se_bwd_apply_bn(int dtype, const void* dy, const float* gate, const float* dpool, void* dx,
+                                    void* dskip, int B, int HW, int C, float skip_scale, float branch_scale,
+                                    int acc_dskip, const void* xb, const float* scale, const float* shift, int act,
+                                    float* partials, void* stream) {
+    if (int e = check_c("se_bwd_apply_bn", C)) return e;
+    NVAE_REQUIRE(B > 0 && HW > 0 && aligned16(dy) && aligned16(dx) && aligned16(dskip) && aligned16(gate) &&
+                 aligned16(dpool) && aligned16(xb) && scale && shift && partials, "se_bwd_apply_bn: bad shape/alignment");
+    NVAE_REQUIRE(dskip || !acc_dskip, "se_bwd_apply_bn: acc_dskip without dskip");
+    NVAE_REQUIRE(act == ACT_NONE || act == ACT_SWISH, "se_bwd_apply_bn: act %d unsupported", act);
+    const long rows = (long)B * HW;
+    const int S = nvae_reduce_splits(rows, C);
+    const long rpb = (rows + S - 1) / S;
+    dim3 grid((C + 63) / 64, S);
+    DISPATCH_T(dtype, hipLaunchKernelGGL((k_se_bwd_apply_bn<T>), grid, RED_THREADS, 0, (hipStream_t)stream, (const T*)dy, gate, dpool, (T*)dx, (T*)dskip, rows, C, HW, (int)rpb, skip_scale, branch_scale, acc_dskip, (const T*)xb, scale, shift, act, partials);)
+    NVAE_LAUNCH_CHECK("se_bwd_apply_bn");
+    return NVAE_OK;
+}

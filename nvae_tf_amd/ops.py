@@ -425,14 +425,27 @@ def se_residual(ctx: Ctx, x: Var, se, skip: Var, skip_scale: float, branch_scale
             ctx.side_launch(lambda: call("nvae_se_wgrad", ptr(pooled), ptr(hidden), ptr(scratch), B, HW, Cc, Hd,
                                          gp + se.w1.off * 4, gp + se.b1.off * 4, gp + se.w2.off * 4,
                                          gp + se.b2.off * 4), pooled, hidden, scratch)
+            src = x.bn_src
+            fuse = FUSE_BN_BWD and src is not None and x.uses == 1 and x.g is None
             gx, accx = ctx.grad_of(x)
             if skip.needs_grad:
                 gs, accs = ctx.grad_of(skip)
                 gs_ptr = ptr(gs)
             else:
                 gs_ptr, accs = None, 0
-            call("nvae_se_bwd_apply", ctx.dt, ptr(y.g), ptr(gate), ptr(dpool), ptr(gx), gs_ptr, B, HW, Cc,
-                 skip_scale, branch_scale, accx, accs)
+            if fuse:
+                # x = act(BN(xb)) with this SE as its only consumer: dx is final, reduce the BN backward sums here
+                S = L.load().nvae_reduce_splits(B * HW, Cc)
+                src["partials"] = ctx.empty((S, 2, Cc), torch.float32)
+                src["k0k1"] = ctx.empty((2, Cc), torch.float32)
+                src["mtiles"] = S
+                call("nvae_se_bwd_apply_bn", ctx.dt, ptr(y.g), ptr(gate), ptr(dpool), ptr(gx), gs_ptr, B, HW, Cc,
+                     skip_scale, branch_scale, accs, ptr(src["x"]), src["scale"], src["shift"], src["act"],
+                     ptr(src["partials"]))
+                src["fused"] = True
+            else:
+                call("nvae_se_bwd_apply", ctx.dt, ptr(y.g), ptr(gate), ptr(dpool), ptr(gx), gs_ptr, B, HW, Cc,
+                     skip_scale, branch_scale, accx, accs)
         ctx.tape.append(bwd)
     return y
 
