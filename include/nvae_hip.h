@@ -153,6 +153,19 @@ int nvae_bn_eval_prepare(const float* gamma, const float* beta, const float* run
                          float* mean, float* invstd, void* stream);
 int nvae_bn_apply(int dtype, const void* x, void* y, long rows, int C, const float* scale,
                   const float* shift, int act, void* stream);
+/* nvae_bn_finalize_s + nvae_bn_apply in ONE launch for a statistics slab that another kernel produced
+ * (conv / depthwise / SE epilogues): every workgroup sums its own 64-channel strip of the slab, the
+ * first row of workgroups also publishes scale/shift/mean/invstd and updates the moving statistics.  */
+int nvae_bn_apply_fin(int dtype, const void* x, void* y, long rows, int C, const float* partials, int S,
+                      const float* gamma, const float* beta, float* running_mean, float* running_var,
+                      float momentum, float eps, float* scale, float* shift, float* mean, float* invstd,
+                      int act, void* stream);
+/* nvae_bn_bwd_finalize_s + nvae_bn_bwd_apply in ONE launch (slab from nvae_conv_gemm_bnbwd /
+ * nvae_se_bwd_apply_bn): dgamma +=, dbeta +=, dx (+)= scale*dpre + k1*x + k0.                       */
+int nvae_bn_bwd_apply_fin(int dtype, const void* x, const void* dy, void* dx, long rows, int C,
+                          const float* partials, int S, const float* scale, const float* shift,
+                          const float* mean, const float* invstd, float* dgamma, float* dbeta, int act,
+                          int frozen, int accumulate, void* stream);
 /* partials[S][2][C] <- per-split (sum dpre, sum dpre*x); dpre = dy * act'(scale*x + shift).      */
 int nvae_bn_bwd_reduce(int dtype, const void* x, const void* dy, long rows, int C, const float* scale,
                        const float* shift, int act, float* partials, void* stream);

@@ -64,6 +64,8 @@ _SIGS = {
     "nvae_bn_eval_prepare": [_p, _p, _p, _p, _i, _f, _p, _p, _p, _p],
     "nvae_bn_apply": [_i, _p, _p, _l, _i, _p, _p, _i],
     "nvae_bn_bwd_reduce": [_i, _p, _p, _l, _i, _p, _p, _i, _p],
+    "nvae_bn_apply_fin": [_i, _p, _p, _l, _i, _p, _i, _p, _p, _p, _p, _f, _f, _p, _p, _p, _p, _i],
+    "nvae_bn_bwd_apply_fin": [_i, _p, _p, _p, _l, _i, _p, _i, _p, _p, _p, _p, _p, _p, _i, _i, _i],
     "nvae_bn_stats_fin": [_i, _p, _l, _i, _p, _p, _p, _p, _p, _p, _f, _f, _p, _p, _p, _p],
     "nvae_bn_bwd_reduce_fin": [_i, _p, _p, _l, _i, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p, _i],
     "nvae_bn_bwd_finalize": [_p, _l, _i, _p, _p, _p, _p, _p, _p, _i],

@@ -783,3 +783,138 @@ extern "C" int nvae_se_bwd_apply_bn(int dtype, const void* dy, const float* gate
     NVAE_LAUNCH_CHECK("se_bwd_apply_bn");
     return NVAE_OK;
 }
+
+// ---- apply passes that finish the reduction themselves ---------------------------------------------
+// When the slab partials come from another kernel (conv / depthwise / SE epilogues), a separate finalize
+// launch costs ~5 us plus its dependency edge, 380 times per step.  These apply kernels are
+// strip-structured instead (a workgroup owns 64 channels x a row range): every workgroup first sums its
+// strip's slab rows itself (one memory round trip, bn_slab_sum64) and derives the 64 coefficients into
+// LDS; the workgroups with blockIdx.y == 0 also publish them (and update the moving statistics /
+// parameter gradients) for the later passes.
+template <typename T>
+__global__ __launch_bounds__(RED_THREADS) void k_bn_apply_fin(
+    const T* __restrict__ x, T* __restrict__ y, long rows, int C, int rows_per_block,
+    const float* __restrict__ partials, int S, BnFinArgs a, int act) {
+    __shared__ float s_sc[64], s_sh[64];
+    {
+        int c; float s1, s2;
+        if (bn_slab_sum64(partials, S, C, blockIdx.x * 64, c, s1, s2)) {
+            const float m = s1 * a.inv_n;
+            const float var = fmaxf(s2 * a.inv_n - m * m, 0.f);
+            const float is = rsqrtf(var + a.eps);
+            const float sc = a.gamma[c] * is, sh = a.beta[c] - m * sc;
+            s_sc[c & 63] = sc; s_sh[c & 63] = sh;
+            if (blockIdx.y == 0) {
+                a.scale[c] = sc; a.shift[c] = sh; a.mean[c] = m; a.invstd[c] = is;
+                a.rm[c] = a.rm[c] * a.momentum + m * (1.f - a.momentum);
+                a.rv[c] = a.rv[c] * a.momentum + var * (1.f - a.momentum);
+            }
+        }
+    }
+    __syncthreads();
+    const int TGS = C >= 64 ? 8 : (C > 16 ? (C > 32 ? 8 : 4) : (C > 8 ? 2 : 1));
+    const int RL = RED_THREADS / TGS;
+    const int tg = threadIdx.x % TGS, rl = threadIdx.x / TGS;
+    const int c0 = blockIdx.x * 64 + tg * 8;
+    if (c0 >= C) return;
+    float sc[8], sh[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { sc[j] = s_sc[tg * 8 + j]; sh[j] = s_sh[tg * 8 + j]; }
+    const long r0 = (long)blockIdx.y * rows_per_block;
+    long r1 = r0 + rows_per_block;
+    if (r1 > rows) r1 = rows;
+    for (long r = r0 + rl; r < r1; r += RL) {
+        float v[8];
+        V8<T>::ld(x + r * (long)C + c0, v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float p = v[j] * sc[j] + sh[j];
+            v[j] = (act == ACT_SWISH) ? swishf_(p) : p;
+        }
+        V8<T>::st(y + r * (long)C + c0, v);
+    }
+}
+
+extern "C" int nvae_bn_apply_fin(int dtype, const void* x, void* y, long rows, int C, const float* partials, int S,
+                                 const float* gamma, const float* beta, float* rm, float* rv, float momentum,
+                                 float eps, float* scale, float* shift, float* mean, float* invstd, int act,
+                                 void* stream) {
+    if (int e = check_c("bn_apply_fin", C)) return e;
+    NVAE_REQUIRE(rows > 0 && S > 0 && aligned16(x) && aligned16(y) && partials && gamma && beta && rm && rv && scale &&
+                 shift && mean && invstd, "bn_apply_fin: bad rows/alignment/null argument");
+    NVAE_REQUIRE(act == ACT_NONE || act == ACT_SWISH, "bn_apply_fin: act %d unsupported", act);
+    BnFinArgs f{};
+    f.inv_n = 1.0f / (float)rows; f.gamma = gamma; f.beta = beta; f.rm = rm; f.rv = rv; f.momentum = momentum;
+    f.eps = eps; f.scale = scale; f.shift = shift; f.mean = mean; f.invstd = invstd;
+    const int S2 = nvae_reduce_splits(rows, C);
+    const long rpb = (rows + S2 - 1) / S2;
+    dim3 grid((C + 63) / 64, S2);
+    DISPATCH_T(dtype, hipLaunchKernelGGL((k_bn_apply_fin<T>), grid, RED_THREADS, 0, (hipStream_t)stream, (const T*)x, (T*)y, rows, C, (int)rpb, partials, S, f, act);)
+    NVAE_LAUNCH_CHECK("bn_apply_fin");
+    return NVAE_OK;
+}
+
+template <typename T>
+__global__ __launch_bounds__(RED_THREADS) void k_bn_bwd_apply_fin(
+    const T* __restrict__ x, const T* __restrict__ dy, T* dx, long rows, int C, int rows_per_block,
+    const float* __restrict__ partials, int S, BnFinArgs a, const float* __restrict__ shift, int act, int acc) {
+    __shared__ float s_sc[64], s_sh[64], s_k0[64], s_k1[64];
+    {
+        int c; float s1, s2;
+        if (bn_slab_sum64(partials, S, C, blockIdx.x * 64, c, s1, s2)) {
+            const float m = a.mean[c], is = a.invstd[c], sc = a.scale[c];
+            const float dg = is * (s2 - m * s1);
+            const float k1 = a.frozen ? 0.f : -sc * dg * is * a.inv_n;
+            const float k0 = a.frozen ? 0.f : -sc * s1 * a.inv_n - k1 * m;
+            s_sc[c & 63] = sc; s_sh[c & 63] = shift[c]; s_k0[c & 63] = k0; s_k1[c & 63] = k1;
+            if (blockIdx.y == 0) { a.dgamma[c] += dg; a.dbeta[c] += s1; }
+        }
+    }
+    __syncthreads();
+    const int TGS = C >= 64 ? 8 : (C > 16 ? (C > 32 ? 8 : 4) : (C > 8 ? 2 : 1));
+    const int RL = RED_THREADS / TGS;
+    const int tg = threadIdx.x % TGS, rl = threadIdx.x / TGS;
+    const int c0 = blockIdx.x * 64 + tg * 8;
+    if (c0 >= C) return;
+    float sc[8], sh[8], k0[8], k1[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        sc[j] = s_sc[tg * 8 + j]; sh[j] = s_sh[tg * 8 + j]; k0[j] = s_k0[tg * 8 + j]; k1[j] = s_k1[tg * 8 + j];
+    }
+    const long r0 = (long)blockIdx.y * rows_per_block;
+    long r1 = r0 + rows_per_block;
+    if (r1 > rows) r1 = rows;
+    for (long r = r0 + rl; r < r1; r += RL) {
+        const long off = r * (long)C + c0;
+        float v[8], g[8], o[8];
+        V8<T>::ld(x + off, v);
+        V8<T>::ld(dy + off, g);
+        if (acc) V8<T>::ld(dx + off, o);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float dpre = g[j];
+            if (act == ACT_SWISH) dpre *= dswishf_(v[j] * sc[j] + sh[j]);
+            o[j] = (acc ? o[j] : 0.f) + sc[j] * dpre + k1[j] * v[j] + k0[j];
+        }
+        V8<T>::st(dx + off, o);
+    }
+}
+
+extern "C" int nvae_bn_bwd_apply_fin(int dtype, const void* x, const void* dy, void* dx, long rows, int C,
+                                     const float* partials, int S, const float* scale, const float* shift,
+                                     const float* mean, const float* invstd, float* dgamma, float* dbeta, int act,
+                                     int frozen, int accumulate, void* stream) {
+    if (int e = check_c("bn_bwd_apply_fin", C)) return e;
+    NVAE_REQUIRE(rows > 0 && S > 0 && aligned16(x) && aligned16(dy) && aligned16(dx) && partials && scale && shift &&
+                 mean && invstd && dgamma && dbeta, "bn_bwd_apply_fin: bad rows/alignment/null argument");
+    NVAE_REQUIRE(act == ACT_NONE || act == ACT_SWISH, "bn_bwd_apply_fin: act %d unsupported", act);
+    BnFinArgs f{};
+    f.inv_n = 1.0f / (float)rows; f.scale = (float*)scale; f.mean = (float*)mean; f.invstd = (float*)invstd;
+    f.dgamma = dgamma; f.dbeta = dbeta; f.frozen = frozen;
+    const int S2 = nvae_reduce_splits(rows, C);
+    const long rpb = (rows + S2 - 1) / S2;
+    dim3 grid((C + 63) / 64, S2);
+    DISPATCH_T(dtype, hipLaunchKernelGGL((k_bn_bwd_apply_fin<T>), grid, RED_THREADS, 0, (hipStream_t)stream, (const T*)x, (const T*)dy, (T*)dx, rows, C, (int)rpb, partials, S, f, shift, act, accumulate);)
+    NVAE_LAUNCH_CHECK("bn_bwd_apply_fin");
+    return NVAE_OK;
+}

@@ -39,6 +39,7 @@ class Var:
 
 
 FUSED_FIN = os.environ.get("NVAE_BN_FUSED_FIN", "1") != "0"
+APPLY_FIN = os.environ.get("NVAE_BN_APPLY_FIN", "1") != "0"   # slab -> coefficients inside the apply kernels
 SE_STATS = os.environ.get("NVAE_SE_STATS", "1") != "0"         # BN statistics out of the SE + residual kernel
 FUSE_BN_BWD = os.environ.get("NVAE_BN_BWD_FUSE", "1") != "0"   # BN backward sums in the dgrad epilogue
 
@@ -332,7 +333,14 @@ def bn_act(ctx: Ctx, x: Var, bn, act: int = L.ACT_NONE) -> Var:
     gamma, beta = ptr(ps.view(bn.gamma)), ptr(ps.view(bn.beta))
     rm, rv = ptr(ps.sview(bn.rm)), ptr(ps.sview(bn.rv))
     S = L.load().nvae_reduce_splits(rows, Cc)
-    if ctx.training and x.stats is not None:
+    y = None
+    if ctx.training and x.stats is not None and APPLY_FIN:
+        # statistics slab from the producing kernel: finalize + apply in one launch
+        slab, Sx = x.stats
+        y = Var(ctx.empty(x.t.shape), x.needs_grad)
+        call("nvae_bn_apply_fin", ctx.dt, ptr(x.t), ptr(y.t), rows, Cc, ptr(slab), Sx, gamma, beta, rm, rv,
+             BN_MOMENTUM, BN_EPS, scale, shift, mean, invstd, act)
+    elif ctx.training and x.stats is not None:
         slab, Sx = x.stats
         call("nvae_bn_finalize_s", ptr(slab), Sx, rows, Cc, gamma, beta, rm, rv, BN_MOMENTUM, BN_EPS, scale,
              shift, mean, invstd)
@@ -347,8 +355,9 @@ def bn_act(ctx: Ctx, x: Var, bn, act: int = L.ACT_NONE) -> Var:
                  shift, mean, invstd)
     else:
         call("nvae_bn_eval_prepare", gamma, beta, rm, rv, Cc, BN_EPS, scale, shift, mean, invstd)
-    y = Var(ctx.empty(x.t.shape), x.needs_grad)
-    call("nvae_bn_apply", ctx.dt, ptr(x.t), ptr(y.t), rows, Cc, scale, shift, act)
+    if y is None:
+        y = Var(ctx.empty(x.t.shape), x.needs_grad)
+        call("nvae_bn_apply", ctx.dt, ptr(x.t), ptr(y.t), rows, Cc, scale, shift, act)
     if ctx.record:
         frozen = 0 if ctx.training else 1      # tf_literal: backward through moving-statistics BN
         dgamma = ptr(ps.grads) + bn.gamma.off * 4
@@ -358,8 +367,13 @@ def bn_act(ctx: Ctx, x: Var, bn, act: int = L.ACT_NONE) -> Var:
         y.bn_src = info
 
         def bwd():
+            if info["fused"] and APPLY_FIN and x.needs_grad:
+                # the sums were produced by the consumer's backward kernel: finalize + apply in one launch
+                g, acc = ctx.grad_of(x)
+                call("nvae_bn_bwd_apply_fin", ctx.dt, ptr(x.t), ptr(y.g), ptr(g), rows, Cc, ptr(info["partials"]),
+                     info["mtiles"], scale, shift, mean, invstd, dgamma, dbeta, act, frozen, acc)
+                return
             if info["fused"]:
-                # the sums were produced by the consumer's data-gradient kernel (conv2d backward)
                 call("nvae_bn_bwd_finalize_s", ptr(info["partials"]), info["mtiles"], rows, Cc, scale, mean, invstd,
                      dgamma, dbeta, ptr(info["k0k1"]), frozen)
                 if x.needs_grad:
