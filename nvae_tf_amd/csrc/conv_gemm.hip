@@ -37,7 +37,7 @@ struct ConvBnBwd {
     BnFinArgs fin;
 };
 
-template <typename T, int BM, int BN, int WM, int WN, typename RowMap>
+template <typename T, int BM, int BN, int WM, int WN, bool BNBWD, typename RowMap>
 __device__ __forceinline__ void conv_epilogue(f32x4 (&acc)[BM / WM / 16][BN / WN / 16], float* lds_f,
                                               const NvaeConvGeom& g, const float* __restrict__ bias,
                                               const T* residual, void* out, int out_f32, int bm, int bn,
@@ -90,7 +90,7 @@ __device__ __forceinline__ void conv_epilogue(f32x4 (&acc)[BM / WM / 16][BN / WN
     constexpr int WCOLS = BN / WN;
     constexpr int SROW = WCOLS + 4;                        // padded f32 row
     constexpr int VPR = WCOLS / 8;                         // 8-column vectors per row
-    if (be.x) {
+    if constexpr (BNBWD) {
         // (b') vector stores with a FIXED column group per lane (so it can keep running column sums):
         //      lane -> (c8 = lane % VPR, row lane rl = lane / VPR), RPP rows of the 16-row slab per pass.
         constexpr int RPP = (64 / VPR) < 16 ? (64 / VPR) : 16;
@@ -249,7 +249,7 @@ __device__ __forceinline__ void conv_epilogue(f32x4 (&acc)[BM / WM / 16][BN / WN
 //   Out-of-image (padding) and out-of-range lanes read a 16-B zero buffer instead of being masked:
 //   LDS-DMA needs every lane to write its slot.
 // =========================================================================================
-template <typename T, int BM, int BN, int WM, int WN, int STAGES, int BKC>
+template <typename T, int BM, int BN, int WM, int WN, int STAGES, int BKC, bool BNBWD>
 __global__ __launch_bounds__(WM* WN * 64) void k_conv_gemm2(
     NvaeConvGeom g, const T* __restrict__ src, const T* __restrict__ wT, int w_ld,
     const float* __restrict__ bias, const T* residual, void* out, int out_f32, int M, int K, int n_tiles,
@@ -383,8 +383,8 @@ __global__ __launch_bounds__(WM* WN * 64) void k_conv_gemm2(
         cur = cur == STAGES - 1 ? 0 : cur + 1;
     }
 
-    conv_epilogue<T, BM, BN, WM, WN>(acc, (float*)lds, g, bias, residual, out, out_f32, bm, bn, stats, vec_epi,
-                                     [&](int r) -> long { int m = bm * BM + r; return m < M ? (long)m : -1L; }, be);
+    conv_epilogue<T, BM, BN, WM, WN, BNBWD>(acc, (float*)lds, g, bias, residual, out, out_f32, bm, bn, stats, vec_epi,
+                                            [&](int r) -> long { int m = bm * BM + r; return m < M ? (long)m : -1L; }, be);
 }
 
 // =========================================================================================
@@ -400,7 +400,7 @@ __global__ __launch_bounds__(WM* WN * 64) void k_conv_gemm2(
 //   Halo rows are [pixel][8 chunks], slot = chunk ^ (row & 7): conflict-free for the 16x16x32 operand
 //   read at ANY row offset (the tap shift moves the 16-row window by kh*20 + kw rows).
 // =========================================================================================
-template <typename T, int BN, int KS, int WM>
+template <typename T, int BN, int KS, int WM, bool BNBWD>
 __global__ __launch_bounds__(WM * 128) void k_conv_halo(
     NvaeConvGeom g, const T* __restrict__ src, const T* __restrict__ wT, int w_ld,
     const float* __restrict__ bias, const T* residual, void* out, int out_f32, int n_tiles, int total_tiles,
@@ -516,8 +516,8 @@ __global__ __launch_bounds__(WM * 128) void k_conv_halo(
         }
         if (++tap == TAPS) { tap = 0; ++cc; }
     }
-    conv_epilogue<T, BM, BN, WM, WN>(acc, (float*)lds, g, bias, residual, out, out_f32, bp, bn, stats, vec_epi,
-                                     [&](int r) -> long { return ((long)b * H + py0 + (r >> 4)) * W + px0 + (r & 15); }, be);
+    conv_epilogue<T, BM, BN, WM, WN, BNBWD>(acc, (float*)lds, g, bias, residual, out, out_f32, bp, bn, stats, vec_epi,
+                                            [&](int r) -> long { return ((long)b * H + py0 + (r >> 4)) * W + px0 + (r & 15); }, be);
 }
 
 #ifndef HALO_WM
@@ -562,21 +562,24 @@ static int launch_conv_gemm(const NvaeConvGeom* g, const void* src, const void* 
     if (conv_halo_ok(sizeof(T) == 2 ? NVAE_BF16 : NVAE_F32, g)) {
         const int pw = g->Win / 16, ppi = (g->Hin / 16) * pw;
         const int mt = g->B * ppi, nt = cdiv(N, 192);
-        if (g->KH == 5)
-            hipLaunchKernelGGL((k_conv_halo<T, 192, 5, HALO_WM>), mt * nt, HALO_WM * 128, 0, s, *g, (const T*)src, (const T*)wT, w_ld, bias,
-                               (const T*)residual, out, out_f32, nt, mt * nt, pw, ppi, zeros, stats, vec_epi, be);
-        else
-            hipLaunchKernelGGL((k_conv_halo<T, 192, 3, 4>), mt * nt, 512, 0, s, *g, (const T*)src, (const T*)wT, w_ld, bias,
-                               (const T*)residual, out, out_f32, nt, mt * nt, pw, ppi, zeros, stats, vec_epi, be);
+#define LAUNCH_HALO(KS_, WM_, F_)                                                                         \
+        hipLaunchKernelGGL((k_conv_halo<T, 192, KS_, WM_, F_>), mt * nt, WM_ * 128, 0, s, *g, (const T*)src,   \
+                           (const T*)wT, w_ld, bias, (const T*)residual, out, out_f32, nt, mt * nt, pw, ppi,  \
+                           zeros, stats, vec_epi, be);
+        if (g->KH == 5) { if (be.x) LAUNCH_HALO(5, HALO_WM, true) else LAUNCH_HALO(5, HALO_WM, false) }
+        else { if (be.x) LAUNCH_HALO(3, 4, true) else LAUNCH_HALO(3, 4, false) }
+#undef LAUNCH_HALO
         return 0;
     }
-#define LAUNCH2(BM_, BN_, WM_, WN_, ST_, BKC_)                                                          \
+#define LAUNCH2F(BM_, BN_, WM_, WN_, ST_, BKC_, F_)                                                     \
     {                                                                                                   \
         int mt = cdiv(M, BM_), nt = cdiv(N, BN_);                                                       \
-        hipLaunchKernelGGL((k_conv_gemm2<T, BM_, BN_, WM_, WN_, ST_, BKC_>), mt * nt, WM_ * WN_ * 64, 0, s, *g, \
+        hipLaunchKernelGGL((k_conv_gemm2<T, BM_, BN_, WM_, WN_, ST_, BKC_, F_>), mt * nt, WM_ * WN_ * 64, 0, s, *g, \
                            (const T*)src, (const T*)wT, w_ld, bias, (const T*)residual, out, out_f32, M, \
                            K, nt, mt * nt, fd_hw, fd_w, zeros, stats, vec_epi, be);                     \
     }
+#define LAUNCH2(BM_, BN_, WM_, WN_, ST_, BKC_)                                                          \
+    { if (be.x) LAUNCH2F(BM_, BN_, WM_, WN_, ST_, BKC_, true) else LAUNCH2F(BM_, BN_, WM_, WN_, ST_, BKC_, false) }
     // Large problems: 128-row tiles, 8 waves; N tile with the least padding (ties -> larger).
     // Small problems (few tiles): 64 x 64 tiles, 4 waves, so that the grid covers the chip.
     const long big_tiles = (long)cdiv(M, 128) * cdiv(N, 128);
@@ -595,6 +598,7 @@ static int launch_conv_gemm(const NvaeConvGeom* g, const void* src, const void* 
         LAUNCH2(64, 64, 2, 2, 3, 8)
     }
 #undef LAUNCH2
+#undef LAUNCH2F
     return 0;
 }
 
