@@ -6,8 +6,6 @@ template <typename T> struct Tr;
 template <> struct Tr<bf16> { static constexpr int VE = 8; };
 template <> struct Tr<float> { static constexpr int VE = 4; };
 
-__device__ __forceinline__ int swz4(int row) { return (0x1320 >> (((row >> 2) & 3) * 4)) & 3; }
-
 // bijective XCD remap (cdna guide T1): consecutive logical tiles land on one XCD
 __device__ __forceinline__ int xcd_remap(int id, int n) {
     int q = n >> 3, r = n & 7, x = id & 7, l = id >> 3;

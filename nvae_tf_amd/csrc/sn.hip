@@ -32,15 +32,40 @@ __global__ void k_sn_rowdot(const float* __restrict__ params, const NvaeConvDesc
     const float* W = params + d.w_off;
     const float* u = sn_state + d.u_off;
     float sq = 0.f;
-    for (int r = wave; r < SN_ROWS; r += 4) {
-        int k = k0 + r;
-        if (k >= d.K) break;
-        float a = 0.f;
-        for (int c = lane; c < d.Cout; c += 64) a += W[(long)k * d.Cout + c] * u[c];
-        a = wave_sum(a);
-        if (lane == 0) {
-            t_out[d.t_off + k] = a;
-            sq += a * a;
+    // a wave owns rows wave, wave+4, wave+8, wave+12 and walks them TOGETHER: four independent
+    // accumulators per lane, u read once per column group, 16-B loads when Cout allows (it always does
+    // on this path: Cout % 8 == 0 except the 1-channel logit head)
+    float a[4] = {0.f, 0.f, 0.f, 0.f};
+    const float* Wr[4];
+    bool rv[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int k = k0 + wave + 4 * q;
+        rv[q] = k < d.K;
+        Wr[q] = W + (long)(rv[q] ? k : k0) * d.Cout;
+    }
+    if ((d.Cout & 3) == 0 && ((size_t)W & 15) == 0 && ((size_t)u & 15) == 0) {
+        for (int c = lane * 4; c < d.Cout; c += 256) {
+            const float4 uv = *(const float4*)(u + c);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 w = *(const float4*)(Wr[q] + c);
+                a[q] += w.x * uv.x + w.y * uv.y + w.z * uv.z + w.w * uv.w;
+            }
+        }
+    } else {
+        for (int c = lane; c < d.Cout; c += 64) {
+            const float uv = u[c];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) a[q] += Wr[q][c] * uv;
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float v = wave_sum(a[q]);
+        if (lane == 0 && rv[q]) {
+            t_out[d.t_off + k0 + wave + 4 * q] = v;
+            sq += v * v;
         }
     }
     if (lane == 0 && sq != 0.f) atomicAdd(nt2 + d.idx, sq);
