@@ -542,6 +542,7 @@ static int conv_gemm_bm(int dtype, const NvaeConvGeom* g) {
     const long w192 = (long)cdiv(N, 192) * 192, w128 = (long)cdiv(N, 128) * 128, w64 = (long)cdiv(N, 64) * 64;
     if ((long)cdiv(M, 256) * cdiv(N, 192) >= 224 && w192 <= w128 && w192 <= w64 && K >= 1024) return 256;
     if (big_tiles >= 192) return 128;
+    if (K >= 512 && (long)cdiv(M, 64) * cdiv(N, 64) <= 160) return 32;
     return 64;
 }
 
@@ -593,7 +594,10 @@ static int launch_conv_gemm(const NvaeConvGeom* g, const void* src, const void* 
         else LAUNCH2(128, 64, 4, 2, 3, 8)
     } else if (K >= 512) {
         // small M: latency-bound K loop -> 8 waves, 128-deep ring steps (half the barriers)
-        LAUNCH2(64, 64, 2, 4, 3, 16)
+        // these are bound by the bytes each CU can pull in ((BM + BN) * K * 2 per workgroup at ~22 B/cycle/CU):
+        // when 64-row tiles leave CUs idle, 32-row tiles use the whole chip and cut the per-CU bytes by 25 %
+        if ((long)cdiv(M, 64) * cdiv(N, 64) <= 160) LAUNCH2(32, 64, 2, 4, 3, 16)
+        else LAUNCH2(64, 64, 2, 4, 3, 16)
     } else {
         LAUNCH2(64, 64, 2, 2, 3, 8)
     }
