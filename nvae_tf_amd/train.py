@@ -39,14 +39,18 @@ def load_checkpoint(model, path):
 
 
 def train(args, model, train_data, test_data, rank=0, world=1):
-    from .util import sample_to_dir
-    best, bad_epochs = float("inf"), 0
+    from .util import EventWriter, sample_to_dir, tile_images
+    best, bad_epochs, best_state = float("inf"), 0, None
     use_graph = not args.no_graph
     captured = False
+    # callbacks.TensorBoard(update_freq="epoch") + the image logger of train.py:20-45, written as real
+    # event files (util.EventWriter) so `tensorboard --logdir` works without TensorFlow on the box
+    tb = EventWriter(args.tensorboard_log_dir) if (args.tensorboard_log_dir and rank == 0) else None
+    tb_img = EventWriter(os.path.join(args.tensorboard_log_dir, "images")) if tb is not None else None
     for epoch in range(args.resume_from, args.epochs):
         model.on_epoch_begin(epoch)
         model.sync_replicas()       # data-parallel: bound the ulp drift of the replicas (models.sync_replicas)
-        t0, seen, losses = time.time(), 0, []
+        t0, seen, logs = time.time(), 0, {"loss": [], "reconstruction_loss": [], "kl_loss": [], "bn_loss": []}
         for i, (images, _) in enumerate(train_data):
             images = images[rank::world] if world > 1 else images       # shard the batch over ranks
             if use_graph and images.shape[0] == args.batch_size // world:
@@ -58,19 +62,37 @@ def train(args, model, train_data, test_data, rank=0, world=1):
                 out = model.train_step(images)
             seen += images.shape[0] * world
             if args.verbose or args.debug or i % 50 == 0:
-                losses.append(float(out["loss"]))
+                for k in logs:
+                    logs[k].append(float(out[k].float().mean()))
         dt = time.time() - t0
+        means = {k: float(np.mean(v)) for k, v in logs.items()}
         if rank == 0:
-            print(f"epoch {epoch}: loss {np.mean(losses):.3f}  {seen / dt:.1f} images/s  beta {model.beta():.3f}")
+            print(f"epoch {epoch}: loss {means['loss']:.3f}  {seen / dt:.1f} images/s  beta {model.beta():.3f}")
+            if tb is not None:
+                for k, v in means.items():
+                    tb.add_scalar("epoch_" + k, v, epoch)
+                tb.add_scalar("images_per_sec", seen / dt, epoch)
             if epoch % args.sample_frequency == 0:
                 sample_to_dir(model, 16, 16, 1.0, os.path.join(args.sample_dir, f"epoch_{epoch}"))
+                if tb_img is not None:
+                    for t in (0.7, 0.8, 0.9, 1.0):      # evaluate.py:15-30: one grid per temperature
+                        imgs, *_ = model.sample(n_samples=16, temperature=t)
+                        tb_img.add_image(f"generated_sample_images temperature={t}", tile_images(imgs), epoch)
             if epoch % args.model_save_frequency == 0:
                 save_checkpoint(model, checkpoint_path(args.model_save_dir, epoch), epoch)
-        if args.patience:          # EarlyStopping on the training loss (train.py:35-38)
-            cur = float(np.mean(losses))
-            best, bad_epochs = (cur, 0) if cur < best else (best, bad_epochs + 1)
+        if args.patience:          # EarlyStopping(patience, restore_best_weights=True) on the training loss (train.py:35-38)
+            cur = means["loss"]
+            if cur < best:
+                best, bad_epochs = cur, 0
+                best_state = (model.ps.params.clone(), model.ps.state.clone())
+            else:
+                bad_epochs += 1
             if bad_epochs > args.patience:
+                if best_state is not None:
+                    model.ps.params.copy_(best_state[0]); model.ps.state.copy_(best_state[1])
                 break
+    if tb is not None:
+        tb.close(); tb_img.close()
     if rank == 0:
         save_checkpoint(model, checkpoint_path(args.model_save_dir, "final"), args.epochs)
 

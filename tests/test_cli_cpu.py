@@ -130,3 +130,17 @@ def test_oracle_dmol_known_answers():
     u_pix = torch.full((1, 1, 1, 3), 0.5, dtype=torch.float64)
     s = dmol_sample(l, M, u_mix, u_pix, t=1.0)
     assert torch.allclose(s[0, 0, 0], torch.tensor([0.3, -0.2, 0.1], dtype=torch.float64) / 2 + 0.5)
+
+
+def test_tensorboard_event_writer_roundtrip(tmp_path):
+    """Event files written without TensorFlow: record framing, masked CRC32-C, protobuf fields."""
+    from nvae_tf_amd.util import EventWriter, crc32c, read_events
+    assert crc32c(b"123456789") == 0xE3069283          # the CRC-32C check value
+    w = EventWriter(str(tmp_path))
+    w.add_scalar("epoch_loss", 123.5, 3)
+    w.add_scalar("epoch_kl_loss", -0.25, 4)
+    w.add_image("grid", torch.rand(8, 8, 1), 4)
+    w.close()
+    ev = read_events(w.path)
+    assert (3, "epoch_loss", 123.5) in ev and (4, "epoch_kl_loss", -0.25) in ev
+    assert any(t == "grid" and v is None and s == 4 for s, t, v in ev)

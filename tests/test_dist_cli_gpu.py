@@ -124,10 +124,14 @@ def test_train_cli_modes(lib, dev, tmp_path, capsys):
     common = ["--synthetic", "--batch_size", "16", "--n_encoder_channels", "16", "--n_decoder_channels", "16",
               "--n_groups_per_scale", "1", "1", "--n_preprocess_cells", "2", "--n_postprocess_cells", "2",
               "--model_save_dir", str(tmp_path / "models"), "--sample_dir", str(tmp_path / "results"),
-              "--dtype", "bf16", "--debug", "--step_based_warmup"]
+              "--tensorboard_log_dir", str(tmp_path / "logs"), "--dtype", "bf16", "--debug", "--step_based_warmup"]
     train.main(train.parse_args(["--mode", "train", "--epochs", "2", "--model_save_frequency", "1",
-                                 "--sample_frequency", "1"] + common))
+                                 "--sample_frequency", "1", "--patience", "5"] + common))
     assert (tmp_path / "models" / "epoch_final.pt").exists() and (tmp_path / "models" / "epoch_1.pt").exists()
+    from nvae_tf_amd.util import read_events
+    ev = read_events(str(next((tmp_path / "logs").glob("events.out.tfevents.*"))))
+    assert {t for _, t, _ in ev} >= {"epoch_loss", "epoch_reconstruction_loss", "epoch_kl_loss", "epoch_bn_loss"}
+    assert len(read_events(str(next((tmp_path / "logs" / "images").glob("events.out.tfevents.*"))))) == 8
     assert len(list((tmp_path / "results" / "epoch_0").iterdir())) == 16
     train.main(train.parse_args(["--mode", "test", "--epochs", "2", "--resume_from", "1", "--binary_eval"] + common))
     out = capsys.readouterr().out
@@ -144,7 +148,7 @@ def test_train_cli_cifar10_synthetic(lib, dev, tmp_path, capsys):
               "--n_decoder_channels", "16", "--n_groups_per_scale", "3", "--n_preprocess_blocks", "1",
               "--n_postprocess_blocks", "1", "--n_preprocess_cells", "2", "--n_postprocess_cells", "2",
               "--model_save_dir", str(tmp_path / "models"), "--sample_dir", str(tmp_path / "results"),
-              "--dtype", "bf16", "--debug", "--step_based_warmup"]
+              "--tensorboard_log_dir", str(tmp_path / "logs"), "--dtype", "bf16", "--debug", "--step_based_warmup"]
     train.main(train.parse_args(["--mode", "train", "--epochs", "1", "--model_save_frequency", "1",
                                  "--sample_frequency", "1"] + common))
     assert (tmp_path / "models" / "epoch_final.pt").exists()
