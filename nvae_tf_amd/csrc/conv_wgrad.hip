@@ -451,7 +451,7 @@ static WgradPlan plan_conv_wgrad(const NvaeConvGeom* g, long scratch_floats) {
     const long flops = 2L * M * K * N;
     WgradPlan p;
     int KT, NTL;
-    if (flops >= (1L << 36) && N >= 128 && K >= 256) { p.cfg = 0; KT = 256; NTL = 128; }
+    if (flops >= (1L << 33) && N >= 128 && K >= 256) { p.cfg = 0; KT = 256; NTL = 128; }
     else if (flops >= (1L << 32) && N >= 128 && K >= 128) { p.cfg = 1; KT = 128; NTL = 128; }
     else { p.cfg = 2; KT = 64; NTL = 64; }
     p.n_tiles = cdiv(N, NTL);
