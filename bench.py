@@ -219,12 +219,19 @@ def main():
         dist.broadcast(model.ps.state, 0)
     x = synthetic_batch(args.batch, 1 + rank, device)
 
-    if args.no_graph:
-        step = lambda: model.train_step(x)
-    else:
-        model.capture_train_step(x.shape, warmup=1)
-        model._static_x.copy_(x.to(dtype))
-        step = lambda: model.train_step_graphed(None)
+    use_graph = not args.no_graph
+    if use_graph:
+        try:
+            model.capture_train_step(x.shape, warmup=1)
+            model._static_x.copy_(x.to(dtype))
+        except Exception as e:      # keep the run alive (and say so in the JSON) rather than lose the measurement
+            print(f"[bench] hipGraph capture failed on rank {rank}: {e!r}; falling back to eager launches", file=sys.stderr)
+            use_graph = False
+        if world > 1:               # all ranks must take the same path (the collectives must match)
+            flag = torch.tensor([1 if use_graph else 0], device=device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            use_graph = bool(int(flag[0]))
+    step = (lambda: model.train_step_graphed(None)) if use_graph else (lambda: model.train_step(x))
 
     for _ in range(args.warmup):
         step()
@@ -265,7 +272,7 @@ def main():
                                    "2 cells/group, 20 latents/group; full train step "
                                    "(SN + fwd + ELBO + bwd + Adamax)",
                        "global_batch": args.batch * world, "batch_per_gpu": args.batch,
-                       "parallelism": f"dp{world}", "hip_graph": not args.no_graph},
+                       "parallelism": f"dp{world}", "hip_graph": use_graph},
             "loss_nats": loss,
             "e2e_mfma_frac": value / world * TRAIN_FLOP_PER_IMG / 1e12 / PEAK_BF16_TFLOPS,
             "roofline": {"bound": "mfma", "kernel": "k_conv_halo<bf16,192,5> (dense 5x5 implicit GEMM of Postprocess, fwd + dgrad)",
