@@ -206,7 +206,7 @@ def main():
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback for the hot path)"
-    device = torch.device(f"cuda:{local}")
+    device = torch.device(f"cuda:{local % max(torch.cuda.device_count(), 1)}")
     torch.cuda.set_device(device)
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     import torch.distributed as dist

@@ -97,8 +97,11 @@ def init_from_env(device_index: Optional[int] = None):
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        backend = "nccl" if torch.cuda.is_available() else "gloo"
-        if backend == "nccl":
-            torch.cuda.set_device(local if device_index is None else device_index)
+        # NVAE_DIST_BACKEND=gloo lets several ranks share one GPU (rehearsal of the multi-rank paths on a
+        # one-GPU box; RCCL itself needs one device per rank)
+        backend = os.environ.get("NVAE_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+        if torch.cuda.is_available():
+            n_dev = max(torch.cuda.device_count(), 1)
+            torch.cuda.set_device((local if device_index is None else device_index) % n_dev)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local

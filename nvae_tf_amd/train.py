@@ -121,6 +121,7 @@ def main(args):
     if args.cpu or not torch.cuda.is_available():
         raise SystemExit("the NVAE hot path runs on an MI355X through libnvae_hip.so; there is no CPU path "
                          "(the CPU oracle under oracle/ is test infrastructure only)")
+    local = local % max(torch.cuda.device_count(), 1)     # several gloo ranks may share a GPU (NVAE_DIST_BACKEND)
     torch.cuda.set_device(local)
     torch.manual_seed(args.seed); random.seed(args.seed); np.random.seed(args.seed)
     if args.dataset == "mnist":
