@@ -276,7 +276,11 @@ __global__ __launch_bounds__(512) void k_wgrad_halo(NvaeConvGeom g, const bf16* 
                                                     int hp_total, const uint4* __restrict__ zeros) {
     constexpr int NT = 512, NTL = 192, CCH = 64;
     constexpr int HW_ = 16 + KS - 1;                     // halo width in pixels
-    constexpr int A_ROWS = 8 * HW_;                      // halo pixels per step (one kernel row)
+    constexpr int HWL = 32;                              // halo row pitch in LDS (pixels): a power of two keeps
+    //                                                      the swizzle key (bits of the pixel index) independent
+    //                                                      of the halo ROW, so every operand address below is a
+    //                                                      per-lane constant + a compile-time offset
+    constexpr int A_ROWS = 8 * HWL;                      // LDS rows per step (one kernel row; columns >= HW_ unused)
     constexpr int A_CHUNKS = (A_ROWS * 8 + 63) / 64 * 64;
     constexpr int A_PASSES = (A_CHUNKS + NT - 1) / NT;
     constexpr int B_CHUNKS = 128 * 24, BCH = B_CHUNKS / NT;   // 6
@@ -302,8 +306,8 @@ __global__ __launch_bounds__(512) void k_wgrad_halo(NvaeConvGeom g, const bf16* 
 #pragma unroll
     for (int i = 0; i < A_PASSES; ++i) {
         const int q = tid + NT * i, hrow = q >> 3, pc = q & 7;
-        a_hy[i] = hrow / HW_; a_hx[i] = hrow - a_hy[i] * HW_;
-        if (hrow >= A_ROWS) a_hy[i] = -1000;            // tail lanes DMA zeros
+        a_hy[i] = hrow / HWL; a_hx[i] = hrow - a_hy[i] * HWL;
+        if (hrow >= A_ROWS || a_hx[i] >= HW_) a_hy[i] = -1000;      // unused columns / tail lanes DMA zeros
         a_col[i] = ((((pc >> 1) ^ seg_s4(hrow)) << 1) | (pc & 1)) * 8;
     }
     // dy tile: chunk q -> pixel q / 24, physical chunk q % 24
@@ -351,6 +355,26 @@ __global__ __launch_bounds__(512) void k_wgrad_halo(NvaeConvGeom g, const bf16* 
     const int nsteps = hp_end - hp_begin;
     const int fr = lane & 15, fq = lane >> 4;
     const int q4 = fr >> 2, p4 = fr & 3;
+    // Per-lane operand offsets.  This lane's two 4-pixel blocks of a 32-pixel k-step are pixels 8*fq + q4 and
+    // + 4 (patch row 0 or 1 of the step, column 0..15); the k-step index only adds a compile-time constant
+    // (2 halo rows / 32 dy pixels), and the swizzle keys depend on the column bits alone.
+    int offA[KS][2][2], offB[3][2];
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk) {
+        const int pl = 8 * fq + q4 + 4 * blk, prow = pl >> 4, pcol = pl & 15;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int seg = wn * 3 + j;
+            const int gsw = seg < 8 ? (seg ^ seg_s8(pl)) : 8 + ((seg - 8) ^ seg_s4(pl));
+            offB[j][blk] = pl * 384 + (gsw << 5) + p4 * 8;
+        }
+#pragma unroll
+        for (int kw = 0; kw < KS; ++kw) {
+            const int h = prow * HWL + pcol + kw;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) offA[kw][i][blk] = h * 128 + (((wk * 2 + i) ^ seg_s4(h)) << 5) + p4 * 8;
+        }
+    }
     if (nsteps > 0) issue(0, hp_begin);
     for (int s = 0; s < nsteps; ++s) {
         wait_vmcnt<0>();
@@ -359,35 +383,26 @@ __global__ __launch_bounds__(512) void k_wgrad_halo(NvaeConvGeom g, const bf16* 
         if (s + 1 < nsteps) issue((s + 1) & 1, hp_begin + s + 1);
         const unsigned char* bufA = lds + (s & 1) * STAGE_BYTES;
         const unsigned char* bufB = bufA + A_BYTES;
-#pragma unroll 1
+#pragma unroll
         for (int ks = 0; ks < 4; ++ks) {                  // 32 pixels per MFMA k-step: patch rows 2ks, 2ks+1
-            // this lane's two 4-pixel blocks: pixels 8*fq + q4 (+4) of the k-step
-            const int pix0 = ks * 32 + 8 * fq + q4, pix1 = pix0 + 4;
             bf16x8 bfr[3];
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
-                const int seg = wn * 3 + j;
-                const int g0 = seg < 8 ? (seg ^ seg_s8(pix0)) : 8 + ((seg - 8) ^ seg_s4(pix0));
-                const int g1 = seg < 8 ? (seg ^ seg_s8(pix1)) : 8 + ((seg - 8) ^ seg_s4(pix1));
                 auto lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-                    (__attribute__((address_space(3))) bf16x4*)(bufB + pix0 * 384 + (g0 << 5) + p4 * 8));
+                    (__attribute__((address_space(3))) bf16x4*)(bufB + offB[j][0] + ks * (32 * 384)));
                 auto hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-                    (__attribute__((address_space(3))) bf16x4*)(bufB + pix1 * 384 + (g1 << 5) + p4 * 8));
+                    (__attribute__((address_space(3))) bf16x4*)(bufB + offB[j][1] + ks * (32 * 384)));
                 bfr[j] = (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
             }
-            // halo rows of the two pixel blocks for tap kw: (row, col + kw)
-            const int hr0 = (pix0 >> 4) * HW_ + (pix0 & 15), hr1 = (pix1 >> 4) * HW_ + (pix1 & 15);
 #pragma unroll
             for (int kw = 0; kw < KS; ++kw) {
-                const int h0 = hr0 + kw, h1 = hr1 + kw;
                 bf16x8 af[2];
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
-                    const int seg = wk * 2 + i;
                     auto lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-                        (__attribute__((address_space(3))) bf16x4*)(bufA + h0 * 128 + ((seg ^ seg_s4(h0)) << 5) + p4 * 8));
+                        (__attribute__((address_space(3))) bf16x4*)(bufA + offA[kw][i][0] + ks * (2 * HWL * 128)));
                     auto hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-                        (__attribute__((address_space(3))) bf16x4*)(bufA + h1 * 128 + ((seg ^ seg_s4(h1)) << 5) + p4 * 8));
+                        (__attribute__((address_space(3))) bf16x4*)(bufA + offA[kw][i][1] + ks * (2 * HWL * 128)));
                     af[i] = (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
                 }
 #pragma unroll
