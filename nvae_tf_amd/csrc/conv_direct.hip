@@ -55,6 +55,60 @@ static int check_geom(const char* who, const NvaeConvGeom* g) {
     return NVAE_OK;
 }
 
+// 1x1 convolutions with at most 32 input channels (forward of the latent half of DecoderSampleCombiner,
+// decoder.py:110-117, accumulated onto the other half's output): a workgroup stages 64 rows of x and the
+// [Cin][64] weight strip in LDS, thread (4 rows, 4 channels) does 16 FMAs per 2 LDS reads.
+template <typename T>
+__global__ __launch_bounds__(256) void k_conv_smallk_fwd(const T* __restrict__ src, int in_ld, int Cin,
+                                                         const float* __restrict__ w, long ws_c, long ws_n,
+                                                         const float* __restrict__ bias, const T* residual,
+                                                         int res_ld, void* out, int out_ld, int out_f32, int Cout,
+                                                         long M) {
+    __shared__ float sx[64][33];
+    __shared__ __attribute__((aligned(16))) float sw[32][64];
+    const int n_base = blockIdx.x * 64;
+    const long m_base = (long)blockIdx.y * 64;
+    for (int q = threadIdx.x; q < 64 * 32; q += 256) {
+        const int r = q >> 5, k = q & 31;
+        sx[r][k] = (m_base + r < M && k < Cin) ? ldf<T>(src + (m_base + r) * in_ld + k) : 0.f;
+    }
+    for (int q = threadIdx.x; q < 32 * 64; q += 256) {
+        const int k = q >> 6, n = q & 63;
+        sw[k][n] = (k < Cin && n_base + n < Cout) ? w[k * ws_c + (long)(n_base + n) * ws_n] : 0.f;
+    }
+    __syncthreads();
+    const int n4 = threadIdx.x & 15, rg = threadIdx.x >> 4;
+    float acc[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[r][e] = 0.f;
+#pragma unroll 4
+    for (int k = 0; k < 32; ++k) {
+        if (k >= Cin) break;
+        const float4 wv = *(const float4*)(&sw[k][n4 * 4]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float xv = sx[rg * 4 + r][k];
+            acc[r][0] += xv * wv.x; acc[r][1] += xv * wv.y; acc[r][2] += xv * wv.z; acc[r][3] += xv * wv.w;
+        }
+    }
+    const int n = n_base + n4 * 4;
+    if (n >= Cout) return;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const long m = m_base + rg * 4 + r;
+        if (m >= M) continue;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float v = acc[r][e] + (bias ? bias[n + e] : 0.f);
+            if (residual) v += ldf<T>(residual + m * res_ld + n + e);
+            if (out_f32) ((float*)out)[m * out_ld + n + e] = v;
+            else stf<T>((T*)out + m * out_ld + n + e, v);
+        }
+    }
+}
+
 extern "C" int nvae_conv_direct(int dtype, const NvaeConvGeom* g, const void* src, const float* w,
                                 long ws_tap, long ws_c, long ws_n, int flip, const float* bias,
                                 const void* residual, void* out, int out_f32, void* stream) {
@@ -62,6 +116,14 @@ extern "C" int nvae_conv_direct(int dtype, const NvaeConvGeom* g, const void* sr
     NVAE_REQUIRE(src && w && out, "conv_direct: NULL pointer");
     NVAE_REQUIRE(!residual || g->res_ld >= g->Cout, "conv_direct: res_ld too small");
     long total = (long)g->B * g->Hout * g->Wout * g->Cout;
+    if (g->KH == 1 && g->KW == 1 && g->stride == 1 && g->div == 1 && g->Cin <= 32 && g->Cout % 4 == 0 &&
+        g->Hin == g->Hout && g->Win == g->Wout) {
+        const long M = (long)g->B * g->Hout * g->Wout;
+        dim3 grid(cdiv(g->Cout, 64), (unsigned)cdiv(M, 64));
+        DISPATCH_T(dtype, hipLaunchKernelGGL((k_conv_smallk_fwd<T>), grid, 256, 0, (hipStream_t)stream, (const T*)src, g->in_ld, g->Cin, w, ws_c, ws_n, bias, (const T*)residual, g->res_ld, out, g->out_ld, out_f32, g->Cout, M);)
+        NVAE_LAUNCH_CHECK("conv_smallk_fwd");
+        return NVAE_OK;
+    }
     long gr = (total + 255) / 256;
     if (gr > 8192) gr = 8192;
     DISPATCH_T(dtype, hipLaunchKernelGGL((k_conv_direct<T>), (int)gr, 256, 0, (hipStream_t)stream, *g, (const T*)src, w, ws_tap, ws_c, ws_n, flip, bias, (const T*)residual, out, out_f32, total);)
