@@ -99,6 +99,13 @@ int nvae_conv_gemm_bnbwd(int dtype, const NvaeConvGeom* g, const void* src, cons
 long nvae_conv_wgrad_scratch(int dtype, const NvaeConvGeom* g);
 int nvae_conv_wgrad(int dtype, const NvaeConvGeom* g, const void* x, const void* dy, float* dw,
                     int dw_ld, float* db, float* scratch, long scratch_floats, void* stream);
+/* nvae_conv_wgrad for n <= 32 layers of the SAME geometry in one launch (the residual towers repeat one
+ * conv shape 10-40 times per step; each of those weight gradients alone is a 10-15 us kernel).  x, dy, dw,
+ * db: host arrays of n device pointers (db: NULL, or a pointer for every layer); scratch: n times
+ * nvae_conv_wgrad_scratch(dtype, g) floats (scratch_floats_per_layer each).                          */
+int nvae_conv_wgrad_batched(int dtype, const NvaeConvGeom* g, int n, const void* const* x,
+                            const void* const* dy, float* const* dw, int dw_ld, float* const* db,
+                            float* scratch, long scratch_floats_per_layer, void* stream);
 /* Scalar fallback for shapes the MFMA path does not take (Cin = 1, 20; Cout = 1).  w is the f32
  * master [KH, KW, *, *] addressed as w[tap*ws_tap + c*ws_c + n*ws_n] (tap order flipped if
  * flip != 0), so the same kernel serves forward and data-gradient.                              */

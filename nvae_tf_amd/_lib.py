@@ -50,6 +50,7 @@ _SIGS = {
     "nvae_conv_gemm_bnbwd": [_i, _p, _p, _p, _i, _p, _p, _p, _p],
     "nvae_conv_wgrad_scratch": None,
     "nvae_conv_wgrad": [_i, _G, _p, _p, _p, _i, _p, _p, _l],
+    "nvae_conv_wgrad_batched": [_i, _G, _i, _p, _p, _p, _i, _p, _p, _l],
     "nvae_conv_direct": [_i, _G, _p, _p, _l, _l, _l, _i, _p, _p, _p, _i],
     "nvae_conv_direct_wgrad": [_i, _G, _p, _p, _p, _i, _p],
     "nvae_colsum": [_i, _p, _l, _i, _i, _p],

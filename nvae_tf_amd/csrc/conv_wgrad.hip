@@ -18,11 +18,27 @@ __device__ __forceinline__ int img_src_chunk(int m, int pc) {
     }
 }
 
+// Layers of one geometry are launched together (nvae_conv_wgrad_batched): blockIdx.z selects the layer's
+// pointers from this by-value table (kernel arguments, no device-side table to upload) and its slab.
+#define WGRAD_BATCH_MAX 32
+struct WgradBatch {
+    const void* x[WGRAD_BATCH_MAX];
+    const void* dy[WGRAD_BATCH_MAX];
+    float* dw[WGRAD_BATCH_MAX];
+    float* db[WGRAD_BATCH_MAX];
+    long slab_stride;               // floats between the layers' slabs
+};
+
 template <typename T, int KT, int NTL, int WK, int WN, int STAGES>
 __global__ __launch_bounds__(WK* WN * 64) void k_conv_wgrad2(
-    NvaeConvGeom g, const T* __restrict__ x, const T* __restrict__ dy, float* dw, int dw_ld, float* db,
+    NvaeConvGeom g, WgradBatch bt, int dw_ld,
     int M, int K, int n_tiles, int m_per_split, FastDiv fd_hw, FastDiv fd_w,
     const uint4* __restrict__ zeros, float* slab) {
+    const T* __restrict__ x = (const T*)bt.x[blockIdx.z];
+    const T* __restrict__ dy = (const T*)bt.dy[blockIdx.z];
+    float* dw = bt.dw[blockIdx.z];
+    float* db = bt.db[blockIdx.z];
+    if (slab) slab += (long)blockIdx.z * bt.slab_stride;
     constexpr int NT = WK * WN * 64;
     constexpr int VE = Tr<T>::VE;
     constexpr int RS = 8 * VE;                      // pixels per ring step
@@ -234,8 +250,10 @@ __global__ __launch_bounds__(WK* WN * 64) void k_conv_wgrad2(
 
 // dw[k*dw_ld + n] += sum_s slab[s][k][n]  (k < K);  db[n] += sum_s slab[s][K][n].  32 outputs per
 // workgroup, 8 lane groups walk the splits in parallel.
-__global__ void k_slab_reduce(const float* __restrict__ slab, int S, int K, int N, float* dw, int dw_ld,
-                              float* db) {
+__global__ void k_slab_reduce(const float* __restrict__ slab, int S, int K, int N, WgradBatch bt, int dw_ld) {
+    float* dw = bt.dw[blockIdx.y];
+    float* db = bt.db[blockIdx.y];
+    slab += (long)blockIdx.y * bt.slab_stride;
     __shared__ float sm[8][32];
     const int ol = threadIdx.x & 31, sl = threadIdx.x >> 5;
     const long total = (long)(K + 1) * N;
@@ -496,24 +514,28 @@ static WgradPlan plan_conv_wgrad(const NvaeConvGeom* g, long scratch_floats) {
 }
 
 template <typename T>
-static int launch_conv_wgrad(const NvaeConvGeom* g, const void* x, const void* dy, float* dw, int dw_ld,
-                             float* db, float* scratch, long scratch_floats, hipStream_t s) {
+static int launch_conv_wgrad(const NvaeConvGeom* g, int n, const void* const* x, const void* const* dy,
+                             float* const* dw, int dw_ld, float* const* db, float* scratch, long scratch_floats,
+                             hipStream_t s) {
     const int M = g->B * g->Hout * g->Wout, K = g->KH * g->KW * g->Cin, N = g->Cout;
     FastDiv fd_hw = make_fastdiv((unsigned)(g->Hout * g->Wout)), fd_w = make_fastdiv((unsigned)g->Wout);
     const uint4* zeros = zero_page();
+    // scratch_floats is the budget PER LAYER: all layers of a batch share one plan
     const WgradPlan p = plan_conv_wgrad<T>(g, scratch ? scratch_floats : 0);
     float* slab = p.slab ? scratch : nullptr;
-    dim3 grid(p.tiles, p.nsplit);
+    WgradBatch bt{};
+    for (int i = 0; i < n; ++i) { bt.x[i] = x[i]; bt.dy[i] = dy[i]; bt.dw[i] = dw[i]; bt.db[i] = db ? db[i] : nullptr; }
+    bt.slab_stride = p.slab ? (long)p.nsplit * (K + 1) * N : 0;
+    dim3 grid(p.tiles, p.nsplit, n);
 #define LAUNCHW(KT_, NTL_, WK_, WN_, ST_)                                                               \
-    hipLaunchKernelGGL((k_conv_wgrad2<T, KT_, NTL_, WK_, WN_, ST_>), grid, WK_ * WN_ * 64, 0, s, *g,    \
-                       (const T*)x, (const T*)dy, dw, dw_ld, db, M, K, p.n_tiles, p.mps, fd_hw, fd_w,   \
-                       zeros, slab);
+    hipLaunchKernelGGL((k_conv_wgrad2<T, KT_, NTL_, WK_, WN_, ST_>), grid, WK_ * WN_ * 64, 0, s, *g, bt,   \
+                       dw_ld, M, K, p.n_tiles, p.mps, fd_hw, fd_w, zeros, slab);
     if (p.cfg == 0) LAUNCHW(256, 128, 4, 2, 3)
     else if (p.cfg == 1) LAUNCHW(128, 128, 2, 2, 3)
     else LAUNCHW(64, 64, 2, 2, 3)
 #undef LAUNCHW
     if (slab)
-        hipLaunchKernelGGL(k_slab_reduce, cdiv((long)(K + 1) * N, 32), 256, 0, s, slab, p.nsplit, K, N, dw, dw_ld, db);
+        hipLaunchKernelGGL(k_slab_reduce, dim3(cdiv((long)(K + 1) * N, 32), n), 256, 0, s, slab, p.nsplit, K, N, bt, dw_ld);
     return 0;
 }
 
@@ -524,20 +546,48 @@ extern "C" long nvae_conv_wgrad_scratch(int dtype, const NvaeConvGeom* g) {
     return p.slab ? (long)p.nsplit * (K + 1) * N : 0;
 }
 
+static int check_wgrad_args(const char* who, int dtype, const NvaeConvGeom* g, int dw_ld) {
+    if (int e = check_geom_mfma(who, g)) return e;
+    const int ve = (dtype == NVAE_BF16) ? 8 : 4;
+    NVAE_REQUIRE(dw_ld >= g->Cout, "%s: dw_ld too small", who);
+    NVAE_REQUIRE(g->Cin % ve == 0 && g->in_ld % ve == 0 && g->Cout % ve == 0 && g->out_ld % ve == 0,
+                 "%s: Cin=%d Cout=%d and their lds must be multiples of %d (use nvae_conv_direct_wgrad)", who, g->Cin, g->Cout, ve);
+    return NVAE_OK;
+}
+
 extern "C" int nvae_conv_wgrad(int dtype, const NvaeConvGeom* g, const void* x, const void* dy, float* dw,
                                int dw_ld, float* db, float* scratch, long scratch_floats, void* stream) {
-    if (int e = check_geom_mfma("conv_wgrad", g)) return e;
-    NVAE_REQUIRE(x && dy && dw && dw_ld >= g->Cout, "conv_wgrad: bad args");
-    const int ve = (dtype == NVAE_BF16) ? 8 : 4;
-    NVAE_REQUIRE(g->Cin % ve == 0 && g->in_ld % ve == 0 && g->Cout % ve == 0 && g->out_ld % ve == 0,
-                 "conv_wgrad: Cin=%d Cout=%d and their lds must be multiples of %d (use nvae_conv_direct_wgrad)", g->Cin, g->Cout, ve);
+    if (int e = check_wgrad_args("conv_wgrad", dtype, g, dw_ld)) return e;
+    NVAE_REQUIRE(x && dy && dw, "conv_wgrad: bad args");
     NVAE_REQUIRE(aligned16(x) && aligned16(dy), "conv_wgrad: x/dy must be 16-B aligned");
     if (wgrad_halo_ok(dtype, g, db)) {
         launch_wgrad_halo(g, x, dy, dw, dw_ld, (hipStream_t)stream);
         NVAE_LAUNCH_CHECK("wgrad_halo");
         return NVAE_OK;
     }
-    DISPATCH_T(dtype, launch_conv_wgrad<T>(g, x, dy, dw, dw_ld, db, scratch, scratch_floats, (hipStream_t)stream);)
+    DISPATCH_T(dtype, launch_conv_wgrad<T>(g, 1, &x, &dy, &dw, dw_ld, db ? &db : nullptr, scratch, scratch_floats, (hipStream_t)stream);)
     NVAE_LAUNCH_CHECK("conv_wgrad");
+    return NVAE_OK;
+}
+
+// n <= 32 layers of the SAME geometry in one launch (the residual towers repeat one conv shape 10-40 times per
+// step and each of those weight gradients is a 10-15 us kernel): x / dy / dw / db are host arrays of n
+// device pointers (db: all NULL or none), scratch holds n * nvae_conv_wgrad_scratch(dtype, g) floats.
+extern "C" int nvae_conv_wgrad_batched(int dtype, const NvaeConvGeom* g, int n, const void* const* x,
+                                       const void* const* dy, float* const* dw, int dw_ld, float* const* db,
+                                       float* scratch, long scratch_floats_per_layer, void* stream) {
+    if (int e = check_wgrad_args("conv_wgrad_batched", dtype, g, dw_ld)) return e;
+    NVAE_REQUIRE(n >= 1 && n <= WGRAD_BATCH_MAX && x && dy && dw, "conv_wgrad_batched: n=%d must be in [1, %d]", n, WGRAD_BATCH_MAX);
+    for (int i = 0; i < n; ++i) {
+        NVAE_REQUIRE(x[i] && dy[i] && dw[i] && aligned16(x[i]) && aligned16(dy[i]), "conv_wgrad_batched: bad pointer in layer %d", i);
+        NVAE_REQUIRE(!db || db[i], "conv_wgrad_batched: db must be given for all layers or none");
+    }
+    if (wgrad_halo_ok(dtype, g, db ? db[0] : nullptr)) {
+        for (int i = 0; i < n; ++i) launch_wgrad_halo(g, x[i], dy[i], dw[i], dw_ld, (hipStream_t)stream);
+        NVAE_LAUNCH_CHECK("wgrad_halo");
+        return NVAE_OK;
+    }
+    DISPATCH_T(dtype, launch_conv_wgrad<T>(g, n, x, dy, dw, dw_ld, db, scratch, scratch_floats_per_layer, (hipStream_t)stream);)
+    NVAE_LAUNCH_CHECK("conv_wgrad_batched");
     return NVAE_OK;
 }

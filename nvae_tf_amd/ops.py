@@ -5,7 +5,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
-from typing import Callable, List, Optional, Tuple
+from typing import Callable, Dict, List, Optional, Tuple
 
 import torch
 
@@ -55,6 +55,7 @@ class Ctx:
         self.side = side_stream
         self.keep: List[torch.Tensor] = []
         self.deferred: List[Callable[[], None]] = []
+        self.wgrad_q: List[tuple] = []      # MFMA conv weight gradients waiting to be launched in same-shape batches
         self.flush_every = int(os.environ.get("NVAE_WGRAD_FLUSH", "64"))
         self.dtype = dtype
         self.dt = L.dtype_code(dtype)
@@ -104,14 +105,58 @@ class Ctx:
         # (its inputs are kept alive; nothing on the main stream overwrites them).
         self.deferred.append(fn)
         self.keep.extend(t for t in keep if t is not None)
-        if len(self.deferred) >= self.flush_every:
+        if len(self.deferred) + len(self.wgrad_q) >= self.flush_every:
             self.flush_side()
 
+    def defer_wgrad(self, gw, x_t: torch.Tensor, dy_t: torch.Tensor, dy_ptr: int, dw: int, dw_ld: int, db):
+        """Queue an MFMA conv weight gradient.  Layers of one geometry (the residual towers repeat a conv shape
+        10-40 times) are launched together by nvae_conv_wgrad_batched when the queue is flushed."""
+        key = (tuple(getattr(gw, f) for f, _ in gw._fields_), dw_ld, db is None)
+        self.wgrad_q.append((key, gw, ptr(x_t), dy_ptr, dw, db))
+        self.keep.extend((x_t, dy_t))
+        if self.side is None or len(self.wgrad_q) + len(self.deferred) >= self.flush_every:
+            self.flush_side()
+
+    def _launch_wgrads(self):
+        groups: Dict[tuple, list] = {}
+        for item in self.wgrad_q:
+            groups.setdefault(item[0], []).append(item)
+        self.wgrad_q.clear()
+        lib = L.load()
+        for key, items in groups.items():
+            gw, dw_ld = items[0][1], key[1]
+            need = lib.nvae_conv_wgrad_scratch(self.dt, C.byref(gw))
+            for i0 in range(0, len(items), 32):
+                chunk = items[i0:i0 + 32]
+                seen, run = set(), []
+                for it in chunk + [None]:            # a weight that appears twice must not share a launch
+                    if it is None or it[4] in seen:
+                        self._launch_wgrad_batch(gw, dw_ld, need, run)
+                        seen, run = set(), []
+                    if it is not None:
+                        seen.add(it[4]); run.append(it)
+
+    def _launch_wgrad_batch(self, gw, dw_ld, need, run):
+        n = len(run)
+        if n == 0:
+            return
+        scratch = self.empty((n * need,), torch.float32) if need else None
+        if scratch is not None:
+            self.keep.append(scratch)
+        arr = lambda idx: (C.c_void_p * n)(*[it[idx] for it in run])
+        has_db = run[0][5] is not None
+        call("nvae_conv_wgrad_batched", self.dt, C.byref(gw), n, arr(2), arr(3), arr(4), dw_ld,
+             arr(5) if has_db else None, ptr(scratch), need)
+
     def flush_side(self):
-        if not self.deferred:
+        if not self.deferred and not self.wgrad_q:
+            return
+        if self.side is None:
+            self._launch_wgrads()
             return
         self.side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(self.side):
+            self._launch_wgrads()
             for fn in self.deferred:
                 fn()
         self.deferred.clear()
@@ -123,8 +168,8 @@ class Ctx:
         hi = len(self.tape) if hi is None else hi
         for fn in reversed(self.tape[lo:hi]):
             fn()
+        self.flush_side()
         if self.side is not None:
-            self.flush_side()
             torch.cuda.current_stream().wait_stream(self.side)   # join before the optimizer / all-reduce
         del self.tape[lo:hi]
         if not self.tape:
@@ -235,10 +280,7 @@ def conv2d(ctx: Ctx, x: Var, conv, *, stride: int = 1, up: int = 1, pad: Optiona
             w_mfma = (cin % ve == 0 and Cx % ve == 0 and cout % ve == 0 and Cy % ve == 0
                       and out_coff % ve == 0)
             if w_mfma:
-                need = L.load().nvae_conv_wgrad_scratch(ctx.dt, C.byref(gw))
-                scratch = ctx.empty((need,), torch.float32) if need else None
-                ctx.side_launch(lambda: call("nvae_conv_wgrad", ctx.dt, C.byref(gw), ptr(x.t), dy_ptr, dw, cout, db,
-                                             ptr(scratch), need), scratch, dy)
+                ctx.defer_wgrad(gw, x.t, dy, dy_ptr, dw, cout, db)
             else:
                 ctx.side_launch(lambda: call("nvae_conv_direct_wgrad", ctx.dt, C.byref(gw), ptr(x.t), dy_ptr, dw,
                                              cout, db), dy)
