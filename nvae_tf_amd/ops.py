@@ -56,7 +56,7 @@ class Ctx:
         self.keep: List[torch.Tensor] = []
         self.deferred: List[Callable[[], None]] = []
         self.wgrad_q: List[tuple] = []      # MFMA conv weight gradients waiting to be launched in same-shape batches
-        self.flush_every = int(os.environ.get("NVAE_WGRAD_FLUSH", "64"))
+        self.flush_every = int(os.environ.get("NVAE_WGRAD_FLUSH", "256"))
         self.dtype = dtype
         self.dt = L.dtype_code(dtype)
         self.ve = 8 if dtype == torch.bfloat16 else 4
