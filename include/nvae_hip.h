@@ -226,6 +226,10 @@ int nvae_se_bwd_apply_bn(int dtype, const void* dy, const float* gate, const flo
  * scratch (they do not feed the data-gradient chain: the host enqueues them on its side stream).   */
 int nvae_se_wgrad(const float* pooled_sum, const float* hidden, const float* scratch, int B, int HW,
                   int C, int Hd, float* dw1, float* db1, float* dw2, float* db2, void* stream);
+/* the same for n <= 32 SE layers of one shape in one launch (host arrays of n device pointers) */
+int nvae_se_wgrad_batched(int n, const float* const* pooled_sum, const float* const* hidden,
+                          const float* const* scratch, int B, int HW, int C, int Hd, float* const* dw1,
+                          float* const* db1, float* const* dw2, float* const* db2, void* stream);
 int nvae_se_bwd_apply(int dtype, const void* dy, const float* gate, const float* dpool, void* dx,
                       void* dskip, int B, int HW, int C, float skip_scale, float branch_scale,
                       int acc_dx, int acc_dskip, void* stream);

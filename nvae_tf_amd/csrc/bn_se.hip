@@ -594,9 +594,19 @@ __global__ void k_se_gate_bwd(const float* __restrict__ r, const float* __restri
 // Stage 2: weight gradients as batch contractions, one thread per output, no atomics.
 //   dW2[h,c] += sum_b hid[b,h]*dpre2[b,c];  db2[c] += sum_b dpre2[b,c]
 //   dW1[c,h] += sum_b p[b,c]*dpre1[b,h];    db1[h] += sum_b dpre1[b,h]
-__global__ void k_se_wgrad(const float* __restrict__ pooled_sum, const float* __restrict__ hidden,
-                           const float* __restrict__ dpre2, const float* __restrict__ dpre1, int B,
-                           float inv_hw, int C, int Hd, float* dw1, float* db1, float* dw2, float* db2) {
+#define SE_BATCH_MAX 32
+struct SeWgradBatch {       // layers of one shape share a launch: blockIdx.y selects the layer
+    const float* pooled[SE_BATCH_MAX]; const float* hidden[SE_BATCH_MAX]; const float* scratch[SE_BATCH_MAX];
+    float* dw1[SE_BATCH_MAX]; float* db1[SE_BATCH_MAX]; float* dw2[SE_BATCH_MAX]; float* db2[SE_BATCH_MAX];
+};
+
+__global__ void k_se_wgrad(SeWgradBatch bt, int B, float inv_hw, int C, int Hd) {
+    const float* __restrict__ pooled_sum = bt.pooled[blockIdx.y];
+    const float* __restrict__ hidden = bt.hidden[blockIdx.y];
+    const float* __restrict__ dpre2 = bt.scratch[blockIdx.y];
+    const float* __restrict__ dpre1 = dpre2 + (long)B * C;
+    float* dw1 = bt.dw1[blockIdx.y]; float* db1 = bt.db1[blockIdx.y];
+    float* dw2 = bt.dw2[blockIdx.y]; float* db2 = bt.db2[blockIdx.y];
     // 32 outputs per workgroup (lanes 0-31: consecutive outputs, coalesced over c), 8 batch lanes
     __shared__ float sm[8][32][2];
     const int ol = threadIdx.x & 31, bl = threadIdx.x >> 5;
@@ -637,9 +647,33 @@ extern "C" int nvae_se_gate_bwd(const float* r, const float* pooled_sum, const f
     float* dpre1 = scratch + (long)B * C;
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(k_se_gate_bwd, B, 256, 0, s, r, gate, hidden, 1.0f / (float)HW, C, Hd, w1, w2, branch_scale, dpre2, dpre1, dpool);
-    if (dw1)
-        hipLaunchKernelGGL(k_se_wgrad, cdiv((long)Hd * C + C + Hd, 32), 256, 0, s, pooled_sum, hidden, dpre2, dpre1, B, 1.0f / (float)HW, C, Hd, dw1, db1, dw2, db2);
+    if (dw1) {
+        SeWgradBatch bt{};
+        bt.pooled[0] = pooled_sum; bt.hidden[0] = hidden; bt.scratch[0] = scratch;
+        bt.dw1[0] = dw1; bt.db1[0] = db1; bt.dw2[0] = dw2; bt.db2[0] = db2;
+        hipLaunchKernelGGL(k_se_wgrad, dim3(cdiv((long)Hd * C + C + Hd, 32), 1), 256, 0, s, bt, B, 1.0f / (float)HW, C, Hd);
+    }
     NVAE_LAUNCH_CHECK("se_gate_bwd");
+    return NVAE_OK;
+}
+
+// The parameter gradients of the two FC layers from the scratch nvae_se_gate_bwd left (dw1 == NULL
+// there): independent of the data-gradient chain, so the caller may enqueue it on another stream.
+extern "C" int nvae_se_wgrad_batched(int n, const float* const* pooled_sum, const float* const* hidden,
+                                     const float* const* scratch, int B, int HW, int C, int Hd, float* const* dw1,
+                                     float* const* db1, float* const* dw2, float* const* db2, void* stream) {
+    NVAE_REQUIRE(B > 0 && HW > 0 && C > 0 && C <= SE_MAX_C && Hd > 0 && Hd <= SE_MAX_H, "se_wgrad: bad shape C=%d Hd=%d", C, Hd);
+    NVAE_REQUIRE(n >= 1 && n <= SE_BATCH_MAX && pooled_sum && hidden && scratch && dw1 && db1 && dw2 && db2,
+                 "se_wgrad: n=%d must be in [1, %d], no NULL table", n, SE_BATCH_MAX);
+    SeWgradBatch bt{};
+    for (int i = 0; i < n; ++i) {
+        NVAE_REQUIRE(pooled_sum[i] && hidden[i] && scratch[i] && dw1[i] && db1[i] && dw2[i] && db2[i], "se_wgrad: NULL pointer in layer %d", i);
+        bt.pooled[i] = pooled_sum[i]; bt.hidden[i] = hidden[i]; bt.scratch[i] = scratch[i];
+        bt.dw1[i] = dw1[i]; bt.db1[i] = db1[i]; bt.dw2[i] = dw2[i]; bt.db2[i] = db2[i];
+    }
+    hipLaunchKernelGGL(k_se_wgrad, dim3(cdiv((long)Hd * C + C + Hd, 32), n), 256, 0, (hipStream_t)stream, bt, B,
+                       1.0f / (float)HW, C, Hd);
+    NVAE_LAUNCH_CHECK("se_wgrad");
     return NVAE_OK;
 }
 
@@ -647,12 +681,7 @@ extern "C" int nvae_se_gate_bwd(const float* r, const float* pooled_sum, const f
 // there): independent of the data-gradient chain, so the caller may enqueue it on another stream.
 extern "C" int nvae_se_wgrad(const float* pooled_sum, const float* hidden, const float* scratch, int B, int HW,
                              int C, int Hd, float* dw1, float* db1, float* dw2, float* db2, void* stream) {
-    NVAE_REQUIRE(B > 0 && HW > 0 && C > 0 && C <= SE_MAX_C && Hd > 0 && Hd <= SE_MAX_H, "se_wgrad: bad shape C=%d Hd=%d", C, Hd);
-    NVAE_REQUIRE(pooled_sum && hidden && scratch && dw1 && db1 && dw2 && db2, "se_wgrad: NULL argument");
-    hipLaunchKernelGGL(k_se_wgrad, cdiv((long)Hd * C + C + Hd, 32), 256, 0, (hipStream_t)stream, pooled_sum, hidden,
-                       scratch, scratch + (long)B * C, B, 1.0f / (float)HW, C, Hd, dw1, db1, dw2, db2);
-    NVAE_LAUNCH_CHECK("se_wgrad");
-    return NVAE_OK;
+    return nvae_se_wgrad_batched(1, &pooled_sum, &hidden, &scratch, B, HW, C, Hd, &dw1, &db1, &dw2, &db2, stream);
 }
 
 // dx (+)= bs * dy * gate + dpool[b,c];   dskip (+)= ss * dy

@@ -56,6 +56,7 @@ class Ctx:
         self.keep: List[torch.Tensor] = []
         self.deferred: List[Callable[[], None]] = []
         self.wgrad_q: List[tuple] = []      # MFMA conv weight gradients waiting to be launched in same-shape batches
+        self.se_q: List[tuple] = []         # SE FC parameter gradients, likewise
         self.flush_every = int(os.environ.get("NVAE_WGRAD_FLUSH", "256"))
         self.dtype = dtype
         self.dt = L.dtype_code(dtype)
@@ -105,7 +106,7 @@ class Ctx:
         # (its inputs are kept alive; nothing on the main stream overwrites them).
         self.deferred.append(fn)
         self.keep.extend(t for t in keep if t is not None)
-        if len(self.deferred) + len(self.wgrad_q) >= self.flush_every:
+        if len(self.deferred) + len(self.wgrad_q) + len(self.se_q) >= self.flush_every:
             self.flush_side()
 
     def defer_wgrad(self, gw, x_t: torch.Tensor, dy_t: torch.Tensor, dy_ptr: int, dw: int, dw_ld: int, db):
@@ -117,7 +118,27 @@ class Ctx:
         if self.side is None or len(self.wgrad_q) + len(self.deferred) >= self.flush_every:
             self.flush_side()
 
+    def defer_se_wgrad(self, shape: tuple, pooled, hidden, scratch, grads: tuple):
+        """Queue the FC parameter gradients of one SE layer (shape = (B, HW, C, Hd)); same-shape layers share a launch."""
+        self.se_q.append((shape, ptr(pooled), ptr(hidden), ptr(scratch)) + tuple(grads))
+        self.keep.extend((pooled, hidden, scratch))
+        if self.side is None or len(self.wgrad_q) + len(self.se_q) + len(self.deferred) >= self.flush_every:
+            self.flush_side()
+
+    def _launch_se_wgrads(self):
+        groups: Dict[tuple, list] = {}
+        for item in self.se_q:
+            groups.setdefault(item[0], []).append(item)
+        self.se_q.clear()
+        for (B, HW, Cc, Hd), items in groups.items():
+            for i0 in range(0, len(items), 32):
+                run = items[i0:i0 + 32]
+                n = len(run)
+                arr = lambda idx: (C.c_void_p * n)(*[it[idx] for it in run])
+                call("nvae_se_wgrad_batched", n, arr(1), arr(2), arr(3), B, HW, Cc, Hd, arr(4), arr(5), arr(6), arr(7))
+
     def _launch_wgrads(self):
+        self._launch_se_wgrads()
         groups: Dict[tuple, list] = {}
         for item in self.wgrad_q:
             groups.setdefault(item[0], []).append(item)
@@ -149,7 +170,7 @@ class Ctx:
              arr(5) if has_db else None, ptr(scratch), need)
 
     def flush_side(self):
-        if not self.deferred and not self.wgrad_q:
+        if not self.deferred and not self.wgrad_q and not self.se_q:
             return
         if self.side is None:
             self._launch_wgrads()
@@ -478,9 +499,8 @@ def se_residual(ctx: Ctx, x: Var, se, skip: Var, skip_scale: float, branch_scale
             call("nvae_se_gate_bwd", ptr(r), ptr(pooled), ptr(gate), ptr(hidden), B, HW, Cc, Hd, w1, w2,
                  branch_scale, None, None, None, None, ptr(dpool), ptr(scratch))
             # the FC parameter gradients are off the data-gradient chain: side stream, like the conv wgrads
-            ctx.side_launch(lambda: call("nvae_se_wgrad", ptr(pooled), ptr(hidden), ptr(scratch), B, HW, Cc, Hd,
-                                         gp + se.w1.off * 4, gp + se.b1.off * 4, gp + se.w2.off * 4,
-                                         gp + se.b2.off * 4), pooled, hidden, scratch)
+            ctx.defer_se_wgrad((B, HW, Cc, Hd), pooled, hidden, scratch,
+                               (gp + se.w1.off * 4, gp + se.b1.off * 4, gp + se.w2.off * 4, gp + se.b2.off * 4))
             src = x.bn_src
             fuse = FUSE_BN_BWD and src is not None and x.uses == 1 and x.g is None
             gx, accx = ctx.grad_of(x)
