@@ -875,7 +875,13 @@ extern "C" int nvae_bn_apply_fin(int dtype, const void* x, void* y, long rows, i
     BnFinArgs f{};
     f.inv_n = 1.0f / (float)rows; f.gamma = gamma; f.beta = beta; f.rm = rm; f.rv = rv; f.momentum = momentum;
     f.eps = eps; f.scale = scale; f.shift = shift; f.mean = mean; f.invstd = invstd;
-    const int S2 = nvae_reduce_splits(rows, C);
+    int S2 = nvae_reduce_splits(rows, C) * 2;            // one row per thread: these passes are latency-bound
+    {
+        const int tgs = C >= 64 ? 8 : (C > 16 ? (C > 32 ? 8 : 4) : (C > 8 ? 2 : 1));
+        const long max_s = rows / (RED_THREADS / tgs);
+        if (S2 > max_s) S2 = (int)max_s;
+        if (S2 < 1) S2 = 1;
+    }
     const long rpb = (rows + S2 - 1) / S2;
     dim3 grid((C + 63) / 64, S2);
     DISPATCH_T(dtype, hipLaunchKernelGGL((k_bn_apply_fin<T>), grid, RED_THREADS, 0, (hipStream_t)stream, (const T*)x, (T*)y, rows, C, (int)rpb, partials, S, f, act);)
@@ -940,7 +946,13 @@ extern "C" int nvae_bn_bwd_apply_fin(int dtype, const void* x, const void* dy, v
     BnFinArgs f{};
     f.inv_n = 1.0f / (float)rows; f.scale = (float*)scale; f.mean = (float*)mean; f.invstd = (float*)invstd;
     f.dgamma = dgamma; f.dbeta = dbeta; f.frozen = frozen;
-    const int S2 = nvae_reduce_splits(rows, C);
+    int S2 = nvae_reduce_splits(rows, C) * 2;            // one row per thread: these passes are latency-bound
+    {
+        const int tgs = C >= 64 ? 8 : (C > 16 ? (C > 32 ? 8 : 4) : (C > 8 ? 2 : 1));
+        const long max_s = rows / (RED_THREADS / tgs);
+        if (S2 > max_s) S2 = (int)max_s;
+        if (S2 < 1) S2 = 1;
+    }
     const long rpb = (rows + S2 - 1) / S2;
     dim3 grid((C + 63) / 64, S2);
     DISPATCH_T(dtype, hipLaunchKernelGGL((k_bn_bwd_apply_fin<T>), grid, RED_THREADS, 0, (hipStream_t)stream, (const T*)x, (const T*)dy, (T*)dx, rows, C, (int)rpb, partials, S, f, shift, act, accumulate);)
