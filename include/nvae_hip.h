@@ -203,6 +203,10 @@ int nvae_se_pool(int dtype, const void* x, int B, int HW, int C, float* pooled_s
 int nvae_se_gate(const float* pooled_sum, int B, int HW, int C, int Hd, const float* w1,
                  const float* b1, const float* w2, const float* b2, float* gate, float* hidden,
                  void* stream);
+/* nvae_se_pool + nvae_se_gate in ONE launch (one workgroup per image; C <= 2048) */
+int nvae_se_pool_gate(int dtype, const void* x, int B, int HW, int C, int Hd, const float* w1,
+                      const float* b1, const float* w2, const float* b2, float* pooled_sum, float* gate,
+                      float* hidden, void* stream);
 int nvae_se_apply(int dtype, const void* x, const void* skip, void* y, int B, int HW, int C,
                   const float* gate, float skip_scale, float branch_scale, void* stream);
 /* nvae_se_apply that also emits the BatchNorm statistics of y (the next residual cell starts with a

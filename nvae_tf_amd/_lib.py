@@ -74,6 +74,7 @@ _SIGS = {
     "nvae_bn_bwd_apply": [_i, _p, _p, _p, _l, _i, _p, _p, _p, _i, _i],
     "nvae_se_pool": [_i, _p, _i, _i, _i, _p],
     "nvae_se_gate": [_p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p],
+    "nvae_se_pool_gate": [_i, _p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p],
     "nvae_se_apply": [_i, _p, _p, _p, _i, _i, _i, _p, _f, _f],
     "nvae_se_apply_stats": [_i, _p, _p, _p, _i, _i, _i, _p, _f, _f, _p],
     "nvae_se_bwd_reduce": [_i, _p, _p, _i, _i, _i, _p],

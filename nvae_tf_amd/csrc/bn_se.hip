@@ -451,6 +451,90 @@ extern "C" int nvae_se_gate(const float* pooled_sum, int B, int HW, int C, int H
     return NVAE_OK;
 }
 
+// Pool + gate in one launch: one workgroup per image sums its own [HW, C] tile (48-96 KB at the tower shapes:
+// 1-2 us at what one CU can pull in) and goes straight on to the two FC layers, instead of a separate
+// pooling launch whose only consumer is this kernel.  pooled_sum is still written (the FC weight gradients
+// need it).  MODE_R: the same for the backward pass, r[b,c] = sum_hw x*dy feeding k_se_gate_bwd's math.
+template <typename T>
+__device__ __forceinline__ void se_image_sums(const T* __restrict__ x, const T* __restrict__ dy, int HW, int C,
+                                              float* __restrict__ p /* LDS [C] */, float* part /* LDS [2048] */) {
+    const int CG = C / 8;                                    // 8-channel groups; C <= 2048 -> CG <= 256
+    const int RLn = 256 / CG;                                // row lanes (>= 1)
+    const int tg = threadIdx.x % CG, rl = threadIdx.x / CG;
+    float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (rl < RLn)
+        for (int r = rl; r < HW; r += RLn) {
+            float v[8];
+            V8<T>::ld(x + (long)r * C + tg * 8, v);
+            if (dy) {
+                float g[8];
+                V8<T>::ld(dy + (long)r * C + tg * 8, g);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) a[j] += v[j] * g[j];
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) a[j] += v[j];
+            }
+        }
+    if (rl < RLn) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) part[rl * C + tg * 8 + j] = a[j];     // RLn * C <= 2048
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float v = 0.f;
+        for (int k = 0; k < RLn; ++k) v += part[k * C + c];
+        p[c] = v;
+    }
+    __syncthreads();
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_se_pool_gate(const T* __restrict__ x, int HW, float inv_hw, int C, int Hd,
+                                                      const float* __restrict__ w1, const float* __restrict__ b1,
+                                                      const float* __restrict__ w2, const float* __restrict__ b2,
+                                                      float* __restrict__ pooled_sum, float* __restrict__ gate,
+                                                      float* __restrict__ hidden) {
+    __shared__ float p[SE_MAX_C];
+    __shared__ float part[2048];
+    __shared__ float hd[SE_MAX_H];
+    const int b = blockIdx.x;
+    se_image_sums<T>(x + (long)b * HW * C, nullptr, HW, C, p, part);
+    for (int c = threadIdx.x; c < C; c += 256) {
+        pooled_sum[(long)b * C + c] = p[c];
+        p[c] *= inv_hw;
+    }
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int h = wave; h < Hd; h += 4) {
+        float a = 0.f;
+        for (int c = lane; c < C; c += 64) a += p[c] * w1[(long)c * Hd + h];
+        a = wave_sum(a);
+        if (lane == 0) {
+            float v = fmaxf(a + b1[h], 0.f);
+            hd[h] = v;
+            hidden[(long)b * Hd + h] = v;
+        }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float a = b2[c];
+        for (int h = 0; h < Hd; ++h) a += hd[h] * w2[(long)h * C + c];
+        gate[(long)b * C + c] = sigmoidf_(a);
+    }
+}
+
+extern "C" int nvae_se_pool_gate(int dtype, const void* x, int B, int HW, int C, int Hd, const float* w1,
+                                 const float* b1, const float* w2, const float* b2, float* pooled_sum,
+                                 float* gate, float* hidden, void* stream) {
+    if (int e = check_c("se_pool_gate", C)) return e;
+    NVAE_REQUIRE(B > 0 && HW > 0 && C <= SE_MAX_C && Hd > 0 && Hd <= SE_MAX_H && aligned16(x) && pooled_sum && gate && hidden,
+                 "se_pool_gate: bad shape C=%d Hd=%d / alignment", C, Hd);
+    DISPATCH_T(dtype, hipLaunchKernelGGL((k_se_pool_gate<T>), B, 256, 0, (hipStream_t)stream, (const T*)x, HW, 1.0f / (float)HW, C, Hd, w1, b1, w2, b2, pooled_sum, gate, hidden);)
+    NVAE_LAUNCH_CHECK("se_pool_gate");
+    return NVAE_OK;
+}
+
 template <typename T>
 __global__ void k_se_apply(const T* __restrict__ x, const T* __restrict__ skip, T* __restrict__ y, long n8,
                            int C8, long hwc8, const float* __restrict__ gate, float ss, float bs) {

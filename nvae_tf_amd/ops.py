@@ -476,8 +476,11 @@ def se_residual(ctx: Ctx, x: Var, se, skip: Var, skip_scale: float, branch_scale
     gate = ctx.empty((B, Cc), torch.float32)
     hidden = ctx.empty((B, Hd), torch.float32)
     w1, b1, w2, b2 = (ptr(ps.view(p)) for p in (se.w1, se.b1, se.w2, se.b2))
-    call("nvae_se_pool", ctx.dt, ptr(x.t), B, HW, Cc, ptr(pooled))
-    call("nvae_se_gate", ptr(pooled), B, HW, Cc, Hd, w1, b1, w2, b2, ptr(gate), ptr(hidden))
+    if Cc <= 2048:
+        call("nvae_se_pool_gate", ctx.dt, ptr(x.t), B, HW, Cc, Hd, w1, b1, w2, b2, ptr(pooled), ptr(gate), ptr(hidden))
+    else:
+        call("nvae_se_pool", ctx.dt, ptr(x.t), B, HW, Cc, ptr(pooled))
+        call("nvae_se_gate", ptr(pooled), B, HW, Cc, Hd, w1, b1, w2, b2, ptr(gate), ptr(hidden))
     y = Var(ctx.empty(x.t.shape))
     if ctx.training and SE_STATS:
         # the consumer is almost always the next cell's BatchNorm: emit its statistics slab here
