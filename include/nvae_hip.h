@@ -226,6 +226,10 @@ int nvae_se_bwd_apply_bn(int dtype, const void* dy, const float* gate, const flo
                          void* dskip, int B, int HW, int C, float skip_scale, float branch_scale,
                          int acc_dskip, const void* xb, const float* scale, const float* shift, int act,
                          float* partials, void* stream);
+/* nvae_se_bwd_reduce + nvae_se_gate_bwd (FC parameter gradients left to nvae_se_wgrad) in ONE launch    */
+int nvae_se_reduce_gate_bwd(int dtype, const void* x, const void* dy, const float* gate, const float* hidden,
+                            int B, int HW, int C, int Hd, const float* w1, const float* w2,
+                            float branch_scale, float* dpool, float* scratch, void* stream);
 /* dw1 == NULL above skips the FC parameter gradients; nvae_se_wgrad computes them later from the same
  * scratch (they do not feed the data-gradient chain: the host enqueues them on its side stream).   */
 int nvae_se_wgrad(const float* pooled_sum, const float* hidden, const float* scratch, int B, int HW,

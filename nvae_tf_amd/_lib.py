@@ -79,6 +79,7 @@ _SIGS = {
     "nvae_se_apply_stats": [_i, _p, _p, _p, _i, _i, _i, _p, _f, _f, _p],
     "nvae_se_bwd_reduce": [_i, _p, _p, _i, _i, _i, _p],
     "nvae_se_gate_bwd": [_p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _f, _p, _p, _p, _p, _p, _p],
+    "nvae_se_reduce_gate_bwd": [_i, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _f, _p, _p],
     "nvae_se_wgrad": [_p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p],
     "nvae_se_wgrad_batched": [_i, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p],
     "nvae_se_bwd_apply": [_i, _p, _p, _p, _p, _p, _i, _i, _i, _f, _f, _i, _i],

@@ -675,6 +675,47 @@ __global__ void k_se_gate_bwd(const float* __restrict__ r, const float* __restri
     }
 }
 
+// k_se_gate_bwd with the per-image reduction r[c] = sum_hw x*dy done in place (one workgroup per image), see
+// k_se_pool_gate.
+template <typename T>
+__global__ __launch_bounds__(256) void k_se_reduce_gate_bwd(const T* __restrict__ x, const T* __restrict__ dy, int HW,
+                                                            const float* __restrict__ gate,
+                                                            const float* __restrict__ hidden, float inv_hw, int C,
+                                                            int Hd, const float* __restrict__ w1,
+                                                            const float* __restrict__ w2, float bs,
+                                                            float* __restrict__ dpre2_out,
+                                                            float* __restrict__ dpre1_out, float* __restrict__ dpool) {
+    __shared__ float dpre2[SE_MAX_C];
+    __shared__ float part[2048];
+    __shared__ float dpre1[SE_MAX_H];
+    const int b = blockIdx.x;
+    se_image_sums<T>(x + (long)b * HW * C, dy + (long)b * HW * C, HW, C, dpre2, part);     // dpre2 <- r
+    for (int c = threadIdx.x; c < C; c += 256) {
+        const float g = gate[(long)b * C + c];
+        const float d = bs * dpre2[c] * g * (1.f - g);
+        dpre2[c] = d;
+        dpre2_out[(long)b * C + c] = d;
+    }
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int h = wave; h < Hd; h += 4) {
+        float a = 0.f;
+        for (int c = lane; c < C; c += 64) a += w2[(long)h * C + c] * dpre2[c];
+        a = wave_sum(a);
+        if (lane == 0) {
+            const float d = hidden[(long)b * Hd + h] > 0.f ? a : 0.f;
+            dpre1[h] = d;
+            dpre1_out[(long)b * Hd + h] = d;
+        }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float a = 0.f;
+        for (int h = 0; h < Hd; ++h) a += w1[(long)c * Hd + h] * dpre1[h];
+        dpool[(long)b * C + c] = a * inv_hw;
+    }
+}
+
 // Stage 2: weight gradients as batch contractions, one thread per output, no atomics.
 //   dW2[h,c] += sum_b hid[b,h]*dpre2[b,c];  db2[c] += sum_b dpre2[b,c]
 //   dW1[c,h] += sum_b p[b,c]*dpre1[b,h];    db1[h] += sum_b dpre1[b,h]
@@ -743,6 +784,21 @@ extern "C" int nvae_se_gate_bwd(const float* r, const float* pooled_sum, const f
 
 // The parameter gradients of the two FC layers from the scratch nvae_se_gate_bwd left (dw1 == NULL
 // there): independent of the data-gradient chain, so the caller may enqueue it on another stream.
+// nvae_se_bwd_reduce + nvae_se_gate_bwd (without the FC parameter gradients) in ONE launch; C <= 2048.
+extern "C" int nvae_se_reduce_gate_bwd(int dtype, const void* x, const void* dy, const float* gate,
+                                       const float* hidden, int B, int HW, int C, int Hd, const float* w1,
+                                       const float* w2, float branch_scale, float* dpool, float* scratch,
+                                       void* stream) {
+    if (int e = check_c("se_reduce_gate_bwd", C)) return e;
+    NVAE_REQUIRE(B > 0 && HW > 0 && C <= SE_MAX_C && Hd > 0 && Hd <= SE_MAX_H && aligned16(x) && aligned16(dy) && gate &&
+                 hidden && w1 && w2 && dpool && scratch, "se_reduce_gate_bwd: bad shape C=%d Hd=%d / alignment / NULL", C, Hd);
+    float* dpre2 = scratch;
+    float* dpre1 = scratch + (long)B * C;
+    DISPATCH_T(dtype, hipLaunchKernelGGL((k_se_reduce_gate_bwd<T>), B, 256, 0, (hipStream_t)stream, (const T*)x, (const T*)dy, HW, gate, hidden, 1.0f / (float)HW, C, Hd, w1, w2, branch_scale, dpre2, dpre1, dpool);)
+    NVAE_LAUNCH_CHECK("se_reduce_gate_bwd");
+    return NVAE_OK;
+}
+
 extern "C" int nvae_se_wgrad_batched(int n, const float* const* pooled_sum, const float* const* hidden,
                                      const float* const* scratch, int B, int HW, int C, int Hd, float* const* dw1,
                                      float* const* db1, float* const* dw2, float* const* db2, void* stream) {

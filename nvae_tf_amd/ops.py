@@ -497,10 +497,14 @@ def se_residual(ctx: Ctx, x: Var, se, skip: Var, skip_scale: float, branch_scale
             r = ctx.empty((B, Cc), torch.float32)
             dpool = ctx.empty((B, Cc), torch.float32)
             scratch = ctx.empty((B, Cc + Hd), torch.float32)
-            call("nvae_se_bwd_reduce", ctx.dt, ptr(x.t), ptr(y.g), B, HW, Cc, ptr(r))
             gp = ptr(ps.grads)
-            call("nvae_se_gate_bwd", ptr(r), ptr(pooled), ptr(gate), ptr(hidden), B, HW, Cc, Hd, w1, w2,
-                 branch_scale, None, None, None, None, ptr(dpool), ptr(scratch))
+            if Cc <= 2048:
+                call("nvae_se_reduce_gate_bwd", ctx.dt, ptr(x.t), ptr(y.g), ptr(gate), ptr(hidden), B, HW, Cc, Hd,
+                     w1, w2, branch_scale, ptr(dpool), ptr(scratch))
+            else:
+                call("nvae_se_bwd_reduce", ctx.dt, ptr(x.t), ptr(y.g), B, HW, Cc, ptr(r))
+                call("nvae_se_gate_bwd", ptr(r), ptr(pooled), ptr(gate), ptr(hidden), B, HW, Cc, Hd, w1, w2,
+                     branch_scale, None, None, None, None, ptr(dpool), ptr(scratch))
             # the FC parameter gradients are off the data-gradient chain: side stream, like the conv wgrads
             ctx.defer_se_wgrad((B, HW, Cc, Hd), pooled, hidden, scratch,
                                (gp + se.w1.off * 4, gp + se.b1.off * 4, gp + se.w2.off * 4, gp + se.b2.off * 4))
