@@ -147,7 +147,16 @@ class NVAE:
     def _draw_eps(self, ctx: Ctx, B: int, eps_list):
         if eps_list is not None:
             return [e.to(self.device, torch.float32).contiguous() for e in eps_list]
-        return [ops.randn(ctx, s, self.seed, self.rng_counter) for s in self.eps_shapes(B)]
+        # one Philox launch for all groups (15 launches + 15 counter updates per step otherwise); each group's
+        # slice starts on a 16-B boundary
+        shapes = self.eps_shapes(B)
+        sizes = [(int(np.prod(s)) + 3) // 4 * 4 for s in shapes]
+        flat = ops.randn(ctx, (sum(sizes),), self.seed, self.rng_counter)
+        out, off = [], 0
+        for s, n in zip(shapes, sizes):
+            out.append(flat[off:off + int(np.prod(s))].view(s))
+            off += n
+        return out
 
     # ------------------------------------------------------------------ forward
     def _forward(self, ctx: Ctx, x: torch.Tensor, eps_list, nll=False, mu_sigma_list=None) -> Var:
