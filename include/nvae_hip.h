@@ -39,6 +39,10 @@ extern "C" {
 #define NVAE_OP_SWISH 1  /* activations.swish (preprocess.py:66) */
 #define NVAE_OP_ELU 2    /* layers.ELU (common.py:54, encoder.py:60-65, postprocess.py:27) */
 
+/* Bumped whenever an entry point is added or a signature changes; the Python binding (nvae_tf_amd/_lib.py
+ * ABI_VERSION) refuses to load a library that reports another value. */
+#define NVAE_ABI_VERSION 2
+
 const char* nvae_last_error(void);
 int nvae_abi_version(void);
 

@@ -13,6 +13,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libnvae_hip.so")
 
+ABI_VERSION = 2          # must equal nvae_abi_version() of the loaded library (include/nvae_hip.h NVAE_ABI_VERSION)
 F32, BF16 = 0, 1
 ACT_NONE, ACT_SWISH, ACT_ELU = 0, 1, 2
 OP_AFFINE, OP_SWISH, OP_ELU = 0, 1, 2
@@ -123,6 +124,12 @@ def load():
     lib.nvae_last_error.restype = C.c_char_p
     lib.nvae_last_error.argtypes = []
     lib.nvae_abi_version.restype = C.c_int
+    lib.nvae_abi_version.argtypes = []
+    have = lib.nvae_abi_version()
+    if have != ABI_VERSION:
+        raise RuntimeError(
+            f"{LIB_PATH} is stale: it reports ABI version {have}, this package binds version {ABI_VERSION}. "
+            "Rebuild with `python -m nvae_tf_amd.build --force`.")
     lib.nvae_reduce_splits.restype = C.c_int
     lib.nvae_reduce_splits.argtypes = [_l, _i]
     lib.nvae_dwconv5_stats_rows.restype = C.c_int

@@ -5,7 +5,7 @@
 
 thread_local char g_nvae_err[512] = {0};
 extern "C" const char* nvae_last_error(void) { return g_nvae_err; }
-extern "C" int nvae_abi_version(void) { return 1; }
+extern "C" int nvae_abi_version(void) { return NVAE_ABI_VERSION; }
 
 static inline int ew_grid(long n8) {
     long g = (n8 + 255) / 256;

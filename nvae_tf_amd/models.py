@@ -328,8 +328,8 @@ class NVAE:
         from f32 atomics, whose summation order differs per GPU: replicas drift by ~1 ulp per step.
         train.py calls this at every epoch start (a 250 MB broadcast, ~1 ms over xGMI)."""
         if self.reducer is not None:
-            self.reducer.broadcast_(self.ps.params)
-            self.reducer.broadcast_(self.ps.state)
+            for t in (self.ps.params, self.ps.state, self.ps.adam_m, self.ps.adam_u):
+                self.reducer.broadcast_(t)
 
     def _dp_segments(self) -> bool:
         return self.reducer is not None and self.overlap_allreduce
@@ -379,10 +379,19 @@ class NVAE:
         With a reducer and overlap_allreduce the backward graph is three graphs (postprocess | decoder
         | encoder + preprocess) and each segment's gradient range is all-reduced while the next replays.
         Host-side scalars (lr, beta) reach the kernels through the `hyper` device buffer, noise is
-        drawn in-graph from a device counter, so replays are exact continuations of training."""
+        drawn in-graph from a device counter, so replays are exact continuations of training.
+
+        Capture has no side effects on the training state: the warm-up steps (they load the code objects
+        and size torch's allocator pools before capture) run real kernels on a zero batch, so parameters,
+        Adamax slots, BN moving statistics / SN vectors and the noise counter are snapshotted before and
+        restored after them.  A fresh or resumed run therefore continues exactly where its state says
+        (train.py:46-55,133-135 of the reference: load_weights + initial_epoch)."""
         B = int(batch_shape[0])
         self._static_x = torch.zeros(tuple(batch_shape), device=self.device,
                                      dtype=torch.float32 if self.head == "dmol" else self.dtype)
+        ps = self.ps
+        snap = [(t, t.clone()) for t in (ps.params, ps.state, ps.adam_m, ps.adam_u, self.rng_counter,
+                                         self.coeff, self.am, self.results)]
         self._set_hyper()
         side = torch.cuda.Stream(device=self.device)
         side.wait_stream(torch.cuda.current_stream())
@@ -391,8 +400,11 @@ class NVAE:
                 ctx = self._seg_forward(self._static_x, None)
                 self._seg_backward(ctx, B)
                 self._seg_update()
+            for t, saved in snap:
+                t.copy_(saved)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize(self.device)
+        del snap
         pool = torch.cuda.graph_pool_handle()
         g1, g3 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         # thread_local: a NCCL/RCCL watchdog thread may touch the HIP API while we capture

@@ -39,7 +39,7 @@ def load_checkpoint(model, path):
 
 
 def train(args, model, train_data, test_data, rank=0, world=1):
-    from .util import EventWriter, sample_to_dir, tile_images
+    from .util import EventWriter, sample_to_dir
     best, bad_epochs, best_state = float("inf"), 0, None
     use_graph = not args.no_graph
     captured = False
@@ -74,14 +74,19 @@ def train(args, model, train_data, test_data, rank=0, world=1):
                 tb.add_scalar("images_per_sec", seen / dt, epoch)
             if epoch % args.sample_frequency == 0:
                 sample_to_dir(model, 16, 16, 1.0, os.path.join(args.sample_dir, f"epoch_{epoch}"))
-                if tb_img is not None:
-                    for t in (0.7, 0.8, 0.9, 1.0):      # evaluate.py:15-30: one grid per temperature
-                        imgs, *_ = model.sample(n_samples=16, temperature=t)
-                        tb_img.add_image(f"generated_sample_images temperature={t}", tile_images(imgs), epoch)
+                if tb_img is not None:               # train.py:23-26 of the reference
+                    from .evaluate import save_reconstructions_to_tensorboard, save_samples_to_tensorboard
+                    save_samples_to_tensorboard(epoch, model, tb_img)
+                    save_reconstructions_to_tensorboard(epoch, model, test_data, tb_img)
             if epoch % args.model_save_frequency == 0:
                 save_checkpoint(model, checkpoint_path(args.model_save_dir, epoch), epoch)
         if args.patience:          # EarlyStopping(patience, restore_best_weights=True) on the training loss (train.py:35-38)
             cur = means["loss"]
+            if world > 1:          # every rank must take the same decision, or the survivors hang in the next collective
+                import torch.distributed as dist
+                t = torch.tensor([cur], dtype=torch.float64, device=model.device if dist.get_backend() == "nccl" else "cpu")
+                dist.all_reduce(t)
+                cur = float(t[0]) / world
             if cur < best:
                 best, bad_epochs = cur, 0
                 best_state = (model.ps.params.clone(), model.ps.state.clone())

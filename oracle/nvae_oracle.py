@@ -621,8 +621,10 @@ class OracleNVAE:
         out["grads"] = gd
         return out
 
-    def sample(self, n_samples, temperature, eps_list, greyscale=True):
-        """NVAE.sample, models.py:137-178 (BN inference mode; temperature on z0 only: Q8)."""
+    def sample(self, n_samples, temperature, eps_list, greyscale=True, return_last=False):
+        """NVAE.sample, models.py:137-178 (BN inference mode; temperature on z0 only: Q8).
+        return_last: also return (last_s, last_z): the decoder state entering the last
+        DecoderSampleCombiner and the z it was combined with (what sample_with_z starts from)."""
         B = n_samples
         L = self.cfg.n_latent_per_group
         s = self.P("dec.h").unsqueeze(0).expand(B, -1, -1, -1)
@@ -632,6 +634,7 @@ class OracleNVAE:
         if temperature != 1.0:
             sigma = sigma * temperature
         z = mu + eps_list[0] * sigma
+        last_s, last_z = s, z
         s = self.conv("dec.comb0.conv", torch.cat((s, z), dim=3))
         for layer in self.dec_layers[1:]:
             if layer[0] == "cells":
@@ -643,13 +646,24 @@ class OracleNVAE:
                 mu = softclamp5(d[..., :L])
                 sigma = torch.exp(softclamp5(d[..., L:])) + 1e-2
                 z = mu + eps_list[zi] * sigma
+                last_s, last_z = s, z
                 s = self.conv(f"dec.comb{zi}.conv", torch.cat((s, z), dim=3))
             else:
                 s = self.rescaler(f"dec.up{layer[1]}", s, True, False)
         logits = self.postprocess(s, False)
         if self.cfg.head == "dmol":
-            return logits          # draw pixels with dmol_sample(logits, M, u_mix, u_pix, t)
-        return torch.sigmoid(logits) if greyscale else logits
+            out = logits          # draw pixels with dmol_sample(logits, M, u_mix, u_pix, t)
+        else:
+            out = torch.sigmoid(logits) if greyscale else logits
+        return (out, last_s, last_z) if return_last else out
+
+    def sample_with_z(self, z, s):
+        """NVAE.sample_with_z, models.py:181-189: decoder.groups[-1] (the last DecoderSampleCombiner)
+        on (s, z), then postprocess; Bernoulli mean of the logits."""
+        zi = max(l[1] for l in self.dec_layers if l[0] == "samplecomb") if len(self.dec_layers) > 1 else 0
+        s = self.conv(f"dec.comb{zi}.conv", torch.cat((s, z), dim=3))
+        logits = self.postprocess(s, False)
+        return logits if self.cfg.head == "dmol" else torch.sigmoid(logits)
 
     def neg_log_likelihood(self, x, eps_lists):
         """evaluate.py:111-123 for ONE batch: IWAE bound with k = len(eps_lists)."""

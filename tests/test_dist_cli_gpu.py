@@ -79,10 +79,9 @@ def _dp_worker(rank, world, port, q):
         m = dp.param_marks
         assert m[0] == 0 and m[4] == dp.ps._p_cursor and m[1] < m[2] < m[3] < m[4]
         # graphed path: parameters stay identical across ranks after optimizer steps
+        # (capture is side-effect free: the replicas, built from one seed, are still identical - no re-broadcast)
         dp.capture_train_step(x.shape, warmup=1)
-        dist.broadcast(dp.ps.params, 0); dist.broadcast(dp.ps.state, 0)
-        dp.ps.adam_m.zero_(); dp.ps.adam_u.zero_()
-        for _ in range(2):
+        for _ in range(5):
             out = dp.train_step_graphed(x)
         torch.cuda.synchronize()
         mine = dp.ps.params.clone()
@@ -131,7 +130,10 @@ def test_train_cli_modes(lib, dev, tmp_path, capsys):
     from nvae_tf_amd.util import read_events
     ev = read_events(str(next((tmp_path / "logs").glob("events.out.tfevents.*"))))
     assert {t for _, t, _ in ev} >= {"epoch_loss", "epoch_reconstruction_loss", "epoch_kl_loss", "epoch_bn_loss"}
-    assert len(read_events(str(next((tmp_path / "logs" / "images").glob("events.out.tfevents.*"))))) == 8
+    img_ev = read_events(str(next((tmp_path / "logs" / "images").glob("events.out.tfevents.*"))))
+    # per logged epoch: 4 temperatures x 3 samples (evaluate.py:15-21) + 3 test reconstructions (evaluate.py:24-45)
+    assert len(img_ev) == 2 * (4 * 3 + 3)
+    assert {t.split("/")[0] for _, t, _ in img_ev} == {"t=0.7", "t=0.8", "t=0.9", "t=1.0", "test_reconstruction"}
     assert len(list((tmp_path / "results" / "epoch_0").iterdir())) == 16
     train.main(train.parse_args(["--mode", "test", "--epochs", "2", "--resume_from", "1", "--binary_eval"] + common))
     out = capsys.readouterr().out

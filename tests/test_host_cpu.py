@@ -19,8 +19,19 @@ def test_library_exports_every_declared_symbol(lib):
     assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.nvae_abi_version() == 1
+    m = re.search(r"#define NVAE_ABI_VERSION (\d+)", hdr)
+    assert lib.nvae_abi_version() == int(m.group(1)) == _lib.ABI_VERSION
     assert lib.nvae_reduce_splits(131072, 192) >= 1
+
+
+def test_stale_library_is_refused(monkeypatch):
+    """A libnvae_hip.so built from older sources (it is git-ignored and travels out of band) must not load
+    silently against newer Python signatures."""
+    from nvae_tf_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "ABI_VERSION", _lib.ABI_VERSION + 1)
+    with pytest.raises(RuntimeError, match="stale"):
+        _lib.load()
 
 
 def make(groups, cells, dtype=torch.bfloat16, **kw):
