@@ -246,6 +246,40 @@ int nvae_se_bwd_apply(int dtype, const void* dy, const float* gate, const float*
                       void* dskip, int B, int HW, int C, float skip_scale, float branch_scale,
                       int acc_dx, int acc_dskip, void* stream);
 
+/* ---- SE + residual (+ the BatchNorm in front of it) as one launch per direction: se_fused.hip ------
+ * The tail of every residual cell, y = skip_scale*skip + branch_scale * SE(xs), xs = BN(x)
+ * (decoder.py:135-147 bn4 -> se -> 0.1*inputs + ., postprocess.py:84-88 + 58) or xs = x
+ * (encoder.py:99-107, preprocess.py:100-107).  bn_scale / bn_shift: the BatchNorm's coefficient table
+ * (xs = scale*x + shift; both NULL: no BatchNorm), so its output is never materialised.  A workgroup owns
+ * whole images: pool, both FC layers, gate, residual add and the BatchNorm statistics of y are one pass.
+ * C: a power of two in [8, 2048].  pooled_sum [B,C] (sum over HW of xs), gate [B,C], hidden [B,Hd] are
+ * outputs (the backward pass and nvae_se_wgrad_batched read them).
+ * stats (may be NULL): [nvae_se_fused_rows(B)][2][C] statistics slab of y for the BatchNorm that follows;
+ * fin (may be NULL): that BatchNorm's finalize done by the last workgroup to arrive (see NvaeBnFin).  */
+typedef struct NvaeBnFin {
+    int* counter;               /* >= 1 int, zero at rest (reset by the kernel) */
+    const float* gamma; const float* beta;
+    float* rm; float* rv;       /* moving statistics, updated with Keras momentum semantics */
+    float momentum, eps;
+    float* scale; float* shift; float* mean; float* invstd;     /* [C] each: outputs */
+} NvaeBnFin;
+int nvae_se_fused_rows(int B);
+int nvae_se_fused_fwd(int dtype, const void* x, const float* bn_scale, const float* bn_shift,
+                      const void* skip, void* y, int B, int HW, int C, int Hd, const float* w1,
+                      const float* b1, const float* w2, const float* b2, float skip_scale,
+                      float branch_scale, float* pooled_sum, float* gate, float* hidden, float* stats,
+                      const NvaeBnFin* fin, void* stream);
+/* Backward of the same block: dx (+)= d/dxs, dskip (+)= skip_scale*dy (dskip may be NULL), FC gradient
+ * scratch [B*(C+Hd)] for nvae_se_wgrad_batched.  act: activation of the folded BatchNorm (none / swish).
+ * partials (may be NULL; needs bn_scale and acc_dx == 0): dxs is final, so the BatchNorm-backward sums of
+ * the folded layer are reduced in the same pass: partials[nvae_se_fused_rows(B)][2][C] for
+ * nvae_bn_bwd_apply_fin / nvae_bn_bwd_finalize_s.                                                    */
+int nvae_se_fused_bwd(int dtype, const void* x, const float* bn_scale, const float* bn_shift, int act,
+                      const void* dy, const float* gate, const float* hidden, void* dx, void* dskip, int B,
+                      int HW, int C, int Hd, const float* w1, const float* w2, float skip_scale,
+                      float branch_scale, int acc_dx, int acc_dskip, float* scratch, float* partials,
+                      void* stream);
+
 /* ---- elementwise ------------------------------------------------------------------------- */
 int nvae_unary_fwd(int dtype, int op, const void* x, void* y, long n, float a, float b, void* stream);
 int nvae_unary_bwd(int dtype, int op, const void* x, const void* dy, void* dx, long n, int accumulate,

@@ -34,6 +34,12 @@ class BnBwdFuse(C.Structure):     # NvaeBnBwdFuse
                 ("dgamma", C.c_void_p), ("dbeta", C.c_void_p), ("k0k1", C.c_void_p)]
 
 
+class BnFin(C.Structure):        # NvaeBnFin
+    _fields_ = [("counter", C.c_void_p), ("gamma", C.c_void_p), ("beta", C.c_void_p), ("rm", C.c_void_p),
+                ("rv", C.c_void_p), ("momentum", C.c_float), ("eps", C.c_float), ("scale", C.c_void_p),
+                ("shift", C.c_void_p), ("mean", C.c_void_p), ("invstd", C.c_void_p)]
+
+
 class ConvDesc(C.Structure):
     _fields_ = [("w_off", C.c_longlong), ("wf_off", C.c_longlong), ("wd_off", C.c_longlong),
                 ("u_off", C.c_int), ("t_off", C.c_int), ("K", C.c_int), ("Cout", C.c_int),
@@ -85,6 +91,9 @@ _SIGS = {
     "nvae_se_wgrad_batched": [_i, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p],
     "nvae_se_bwd_apply": [_i, _p, _p, _p, _p, _p, _i, _i, _i, _f, _f, _i, _i],
     "nvae_se_bwd_apply_bn": [_i, _p, _p, _p, _p, _p, _i, _i, _i, _f, _f, _i, _p, _p, _p, _i, _p],
+    "nvae_se_fused_rows": None,
+    "nvae_se_fused_fwd": [_i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _f, _f, _p, _p, _p, _p, _p],
+    "nvae_se_fused_bwd": [_i, _p, _p, _p, _i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _f, _f, _i, _i, _p, _p],
     "nvae_unary_fwd": [_i, _i, _p, _p, _l, _f, _f],
     "nvae_unary_bwd": [_i, _i, _p, _p, _p, _l, _i],
     "nvae_add": [_i, _p, _p, _l, _i],
@@ -132,6 +141,8 @@ def load():
             "Rebuild with `python -m nvae_tf_amd.build --force`.")
     lib.nvae_reduce_splits.restype = C.c_int
     lib.nvae_reduce_splits.argtypes = [_l, _i]
+    lib.nvae_se_fused_rows.restype = C.c_int
+    lib.nvae_se_fused_rows.argtypes = [_i]
     lib.nvae_dwconv5_stats_rows.restype = C.c_int
     lib.nvae_dwconv5_stats_rows.argtypes = [_i, _i, _i, _i, _i]
     lib.nvae_conv_gemm_mtiles.restype = C.c_int

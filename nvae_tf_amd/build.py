@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libnvae_hip.so")
 OBJ = os.path.join(HERE, "build")
-SOURCES = ["elementwise.hip", "bn_se.hip", "loss.hip", "dmol.hip", "dwconv.hip", "conv_direct.hip",
+SOURCES = ["elementwise.hip", "bn_se.hip", "se_fused.hip", "loss.hip", "dmol.hip", "dwconv.hip", "conv_direct.hip",
            "conv_gemm.hip", "conv_wgrad.hip", "sn.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
 

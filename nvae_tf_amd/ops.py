@@ -22,7 +22,7 @@ def same_pad(in_size: int, k: int, s: int) -> Tuple[int, int]:
 
 class Var:
     """An NHWC activation and (lazily) its gradient."""
-    __slots__ = ("t", "g", "needs_grad", "stats", "uses", "bn_src")
+    __slots__ = ("t", "g", "needs_grad", "stats", "uses", "bn_src", "pre")
 
     def __init__(self, t: torch.Tensor, needs_grad: bool = True):
         self.t = t
@@ -32,6 +32,9 @@ class Var:
         self.uses = 0       # ops that consumed this activation (each will add to .g in backward)
         self.bn_src = None  # set by bn_act on its output: what a consumer's data-gradient kernel needs
         #                     to reduce the BatchNorm backward sums in its epilogue (nvae_conv_gemm_bnbwd)
+        self.pre = None     # lazy BatchNorm: the value is act(scale * t + shift) with pre = (scale, shift, act)
+        #                     device pointers; t is the BatchNorm's INPUT.  Only consumers that apply the
+        #                     coefficients themselves (se_residual) may be handed such a Var.
 
     @property
     def shape(self):
@@ -41,6 +44,7 @@ class Var:
 FUSED_FIN = os.environ.get("NVAE_BN_FUSED_FIN", "1") != "0"
 APPLY_FIN = os.environ.get("NVAE_BN_APPLY_FIN", "1") != "0"   # slab -> coefficients inside the apply kernels
 SE_STATS = os.environ.get("NVAE_SE_STATS", "1") != "0"         # BN statistics out of the SE + residual kernel
+SE_FUSED = os.environ.get("NVAE_SE_FUSED", "1") != "0"         # SE + residual (+ the BatchNorm in front) as one launch
 FUSE_BN_BWD = os.environ.get("NVAE_BN_BWD_FUSE", "1") != "0"   # BN backward sums in the dgrad epilogue
 
 
@@ -386,7 +390,10 @@ BN_MOMENTUM = 0.05   # Keras semantics: fraction of the OLD moving statistic kep
 BN_EPS = 1e-5
 
 
-def bn_act(ctx: Ctx, x: Var, bn, act: int = L.ACT_NONE) -> Var:
+def bn_act(ctx: Ctx, x: Var, bn, act: int = L.ACT_NONE, lazy: bool = False) -> Var:
+    """BatchNormalization(momentum=0.05, epsilon=1e-5) (+ Swish).  lazy: the only consumer applies the
+    coefficients itself (se_residual): compute the coefficient table only and hand out the INPUT tensor
+    tagged with it (Var.pre); the normalised activation is never materialised."""
     ps = ctx.ps
     x.uses += 1
     B, H, W, Cc = x.t.shape
@@ -397,7 +404,21 @@ def bn_act(ctx: Ctx, x: Var, bn, act: int = L.ACT_NONE) -> Var:
     rm, rv = ptr(ps.sview(bn.rm)), ptr(ps.sview(bn.rv))
     S = L.load().nvae_reduce_splits(rows, Cc)
     y = None
-    if ctx.training and x.stats is not None and APPLY_FIN:
+    lazy = lazy and SE_FUSED and act == L.ACT_NONE and Cc & (Cc - 1) == 0 and 8 <= Cc <= 2048
+    if lazy:
+        if ctx.training and x.stats is not None:
+            slab, Sx = x.stats
+            call("nvae_bn_finalize_s", ptr(slab), Sx, rows, Cc, gamma, beta, rm, rv, BN_MOMENTUM, BN_EPS, scale,
+                 shift, mean, invstd)
+        elif ctx.training:
+            partials = ctx.empty((S, 2, Cc), torch.float32)
+            call("nvae_bn_stats_fin", ctx.dt, ptr(x.t), rows, Cc, ptr(partials), ctx.counters(), gamma, beta, rm,
+                 rv, BN_MOMENTUM, BN_EPS, scale, shift, mean, invstd)
+        else:
+            call("nvae_bn_eval_prepare", gamma, beta, rm, rv, Cc, BN_EPS, scale, shift, mean, invstd)
+        y = Var(x.t, x.needs_grad)
+        y.pre = (scale, shift, act, coef)
+    elif ctx.training and x.stats is not None and APPLY_FIN:
         # statistics slab from the producing kernel: finalize + apply in one launch
         slab, Sx = x.stats
         y = Var(ctx.empty(x.t.shape), x.needs_grad)
@@ -465,8 +486,13 @@ def bn_act(ctx: Ctx, x: Var, bn, act: int = L.ACT_NONE) -> Var:
 # ------------------------------------------------------------------------------------------
 # Squeeze-Excitation + residual
 # ------------------------------------------------------------------------------------------
+def _se_fused_ok(Cc: int, Hd: int) -> bool:
+    return SE_FUSED and Cc & (Cc - 1) == 0 and 8 <= Cc <= 2048 and Hd <= 128
+
+
 def se_residual(ctx: Ctx, x: Var, se, skip: Var, skip_scale: float, branch_scale: float) -> Var:
-    """y = skip_scale*skip + branch_scale*SE(x)   (SURVEY Q3 for which side carries the 0.1)."""
+    """y = skip_scale*skip + branch_scale*SE(x)   (SURVEY Q3 for which side carries the 0.1).  x may be a lazy
+    BatchNorm output (Var.pre): the fused kernels apply its coefficients on the fly."""
     ps = ctx.ps
     x.uses += 1
     skip.uses += 1
@@ -476,28 +502,73 @@ def se_residual(ctx: Ctx, x: Var, se, skip: Var, skip_scale: float, branch_scale
     gate = ctx.empty((B, Cc), torch.float32)
     hidden = ctx.empty((B, Hd), torch.float32)
     w1, b1, w2, b2 = (ptr(ps.view(p)) for p in (se.w1, se.b1, se.w2, se.b2))
-    if Cc <= 2048:
-        call("nvae_se_pool_gate", ctx.dt, ptr(x.t), B, HW, Cc, Hd, w1, b1, w2, b2, ptr(pooled), ptr(gate), ptr(hidden))
-    else:
-        call("nvae_se_pool", ctx.dt, ptr(x.t), B, HW, Cc, ptr(pooled))
-        call("nvae_se_gate", ptr(pooled), B, HW, Cc, Hd, w1, b1, w2, b2, ptr(gate), ptr(hidden))
+    fused = _se_fused_ok(Cc, Hd)
+    assert x.pre is None or fused, "a lazy BatchNorm output needs the fused SE kernels"
+    pre_scale, pre_shift, pre_act = (x.pre[0], x.pre[1], x.pre[2]) if x.pre is not None else (None, None, L.ACT_NONE)
     y = Var(ctx.empty(x.t.shape))
-    if ctx.training and SE_STATS:
-        # the consumer is almost always the next cell's BatchNorm: emit its statistics slab here
-        S = L.load().nvae_reduce_splits(B * HW, Cc)
-        slab = ctx.empty((S, 2, Cc), torch.float32)
-        call("nvae_se_apply_stats", ctx.dt, ptr(x.t), ptr(skip.t), ptr(y.t), B, HW, Cc, ptr(gate), skip_scale,
-             branch_scale, ptr(slab))
-        y.stats = (slab, S)
+    if fused:
+        # pool + FC + gate + residual add (+ the BatchNorm in front, + the statistics of y) in ONE launch
+        slab = None
+        if ctx.training and SE_STATS:
+            S = L.load().nvae_se_fused_rows(B)
+            slab = ctx.empty((S, 2, Cc), torch.float32)
+            y.stats = (slab, S)
+        call("nvae_se_fused_fwd", ctx.dt, ptr(x.t), pre_scale, pre_shift, ptr(skip.t), ptr(y.t), B, HW, Cc, Hd,
+             w1, b1, w2, b2, skip_scale, branch_scale, ptr(pooled), ptr(gate), ptr(hidden), ptr(slab), None)
     else:
-        call("nvae_se_apply", ctx.dt, ptr(x.t), ptr(skip.t), ptr(y.t), B, HW, Cc, ptr(gate), skip_scale,
-             branch_scale)
+        if Cc <= 2048:
+            call("nvae_se_pool_gate", ctx.dt, ptr(x.t), B, HW, Cc, Hd, w1, b1, w2, b2, ptr(pooled), ptr(gate), ptr(hidden))
+        else:
+            call("nvae_se_pool", ctx.dt, ptr(x.t), B, HW, Cc, ptr(pooled))
+            call("nvae_se_gate", ptr(pooled), B, HW, Cc, Hd, w1, b1, w2, b2, ptr(gate), ptr(hidden))
+        if ctx.training and SE_STATS:
+            # the consumer is almost always the next cell's BatchNorm: emit its statistics slab here
+            S = L.load().nvae_reduce_splits(B * HW, Cc)
+            slab = ctx.empty((S, 2, Cc), torch.float32)
+            call("nvae_se_apply_stats", ctx.dt, ptr(x.t), ptr(skip.t), ptr(y.t), B, HW, Cc, ptr(gate), skip_scale,
+                 branch_scale, ptr(slab))
+            y.stats = (slab, S)
+        else:
+            call("nvae_se_apply", ctx.dt, ptr(x.t), ptr(skip.t), ptr(y.t), B, HW, Cc, ptr(gate), skip_scale,
+                 branch_scale)
     if ctx.record:
         def bwd():
-            r = ctx.empty((B, Cc), torch.float32)
-            dpool = ctx.empty((B, Cc), torch.float32)
             scratch = ctx.empty((B, Cc + Hd), torch.float32)
             gp = ptr(ps.grads)
+            src = x.bn_src
+            fuse = FUSE_BN_BWD and src is not None and x.uses == 1 and x.g is None
+            if fused:
+                gx, accx = ctx.grad_of(x)
+                if skip.needs_grad:
+                    gs, accs = ctx.grad_of(skip)
+                    gs_ptr = ptr(gs)
+                else:
+                    gs_ptr, accs = None, 0
+                part = None
+                if fuse:
+                    # x = act(BN(xb)) with this SE as its only consumer: dx is final, reduce the BN backward sums here
+                    S = L.load().nvae_se_fused_rows(B)
+                    src["partials"] = ctx.empty((S, 2, Cc), torch.float32)
+                    src["k0k1"] = ctx.empty((2, Cc), torch.float32)
+                    src["mtiles"] = S
+                    src["fused"] = True
+                    part = ptr(src["partials"])
+                    assert accx == 0
+                if x.pre is not None:
+                    xin, f_scale, f_shift, f_act = ptr(x.t), pre_scale, pre_shift, pre_act
+                elif fuse:
+                    # materialised BatchNorm output: the sums need the BatchNorm's input and coefficients, and
+                    # r = sum xs*dy is recomputed from them as well (one tensor read instead of two)
+                    xin, f_scale, f_shift, f_act = ptr(src["x"]), src["scale"], src["shift"], src["act"]
+                else:
+                    xin, f_scale, f_shift, f_act = ptr(x.t), None, None, L.ACT_NONE
+                call("nvae_se_fused_bwd", ctx.dt, xin, f_scale, f_shift, f_act, ptr(y.g), ptr(gate), ptr(hidden),
+                     ptr(gx), gs_ptr, B, HW, Cc, Hd, w1, w2, skip_scale, branch_scale, accx, accs, ptr(scratch), part)
+                ctx.defer_se_wgrad((B, HW, Cc, Hd), pooled, hidden, scratch,
+                                   (gp + se.w1.off * 4, gp + se.b1.off * 4, gp + se.w2.off * 4, gp + se.b2.off * 4))
+                return
+            r = ctx.empty((B, Cc), torch.float32)
+            dpool = ctx.empty((B, Cc), torch.float32)
             if Cc <= 2048:
                 call("nvae_se_reduce_gate_bwd", ctx.dt, ptr(x.t), ptr(y.g), ptr(gate), ptr(hidden), B, HW, Cc, Hd,
                      w1, w2, branch_scale, ptr(dpool), ptr(scratch))
@@ -508,8 +579,6 @@ def se_residual(ctx: Ctx, x: Var, se, skip: Var, skip_scale: float, branch_scale
             # the FC parameter gradients are off the data-gradient chain: side stream, like the conv wgrads
             ctx.defer_se_wgrad((B, HW, Cc, Hd), pooled, hidden, scratch,
                                (gp + se.w1.off * 4, gp + se.b1.off * 4, gp + se.w2.off * 4, gp + se.b2.off * 4))
-            src = x.bn_src
-            fuse = FUSE_BN_BWD and src is not None and x.uses == 1 and x.g is None
             gx, accx = ctx.grad_of(x)
             if skip.needs_grad:
                 gs, accs = ctx.grad_of(skip)

@@ -43,7 +43,7 @@ class PostprocessNode:
         x = self.cbs1(ctx, x)
         x = self.cbs5(ctx, x)
         x = ops.conv2d(ctx, x, self.conv3, bias=False, want_stats=True)
-        x = ops.bn_act(ctx, x, self.bn3)
+        x = ops.bn_act(ctx, x, self.bn3, lazy=True)       # applied inside the SE kernel
         return self.se(ctx, x, skip, 1.0, 0.1)      # skip + 0.1 * sequence, postprocess.py:58
 
 

@@ -340,10 +340,15 @@ def test_fused_bn_chain(lib, dev, dtype, case):
 
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
-@pytest.mark.parametrize("shape", [(6, 4, 4, 256), (3, 8, 8, 72), (2, 16, 16, 64)])
-def test_fused_bn_se_chain(lib, dev, dtype, shape):
+@pytest.mark.parametrize("shape", [(6, 4, 4, 256), (3, 8, 8, 72), (2, 16, 16, 64), (130, 4, 4, 128), (2, 32, 32, 32)])
+@pytest.mark.parametrize("lazy", [False, True], ids=["materialised", "lazy"])
+def test_fused_bn_se_chain(lib, dev, dtype, shape, lazy):
     """BN -> SE + residual -> BN: the SE kernel emits the next BatchNorm's statistics, its backward apply
-    reduces the previous BatchNorm's backward sums; both BatchNorms use the finalize-in-apply passes."""
+    reduces the previous BatchNorm's backward sums; both BatchNorms use the finalize-in-apply passes.
+    lazy: the first BatchNorm is applied inside the fused SE kernels (forward and backward) from its
+    coefficient table and its output is never materialised (nor rounded to the activation dtype).
+    (130 images: more than the 128 rows of the fused kernels' statistics slab -> two images per workgroup;
+    72 channels: not a power of two -> the unfused launch sequence.)"""
     from nvae_tf_amd import ops
     from nvae_tf_amd.ops import Var
     from nvae_tf_amd.params import ParamStore
@@ -364,7 +369,8 @@ def test_fused_bn_se_chain(lib, dev, dtype, shape):
         m, v = t.mean((0, 1, 2)), t.var((0, 1, 2), unbiased=False)
         return (t - m) * torch.rsqrt(v + 1e-5) * ga + be
     a = bn_ref(x64, P["bn1.gamma"], P["bn1.beta"])
-    aq = q(a.detach().float(), dtype) + (a - a.detach())
+    really_lazy = lazy and C_ & (C_ - 1) == 0
+    aq = a if really_lazy else q(a.detach().float(), dtype) + (a - a.detach())
     gate = torch.sigmoid(torch.relu(aq.mean((1, 2)) @ P["se.w1"] + P["se.b1"]) @ P["se.w2"] + P["se.b2"])
     r = 0.1 * s64 + aq * gate[:, None, None, :]
     m2, v2 = r.mean((0, 1, 2)), r.var((0, 1, 2), unbiased=False)      # from the f32 values, before rounding
@@ -375,7 +381,8 @@ def test_fused_bn_se_chain(lib, dev, dtype, shape):
     gr = torch.autograd.grad(y_ref, [x64, s64] + [P[n] for n in names], q(dy, dtype))
     ctx = make_ctx(ps, dtype)
     xv, sv = Var(x.to(dev, dtype)), Var(skip.to(dev, dtype))
-    av = ops.bn_act(ctx, xv, bn1, 0)
+    av = ops.bn_act(ctx, xv, bn1, 0, lazy=lazy)
+    assert (av.pre is not None) == really_lazy and (av.t is xv.t) == really_lazy
     rv = ops.se_residual(ctx, av, se, sv, 0.1, 1.0)
     assert rv.stats is not None
     y = ops.bn_act(ctx, rv, bn2, 1)
