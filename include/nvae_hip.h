@@ -139,11 +139,14 @@ int nvae_dwconv5_wgrad(int dtype, const void* x, const void* dy, float* dw, floa
  *      postprocess.py:71,84,107-108, preprocess.py:88-89, common.py:148,165-166 ------------------- */
 /* Row splits S used by the [rows, C] reductions; slabs passed as `partials` hold S*2*C floats.  */
 int nvae_reduce_splits(long rows, int C);
-/* partials[S][2][C] <- per-split (sum x, sum x^2).  No atomics, nothing needs zeroing.          */
+/* partials[S][2][C] <- per-split (sum x, sum x^2).  No atomics, nothing needs zeroing.
+ * dtype == NVAE_F32: the slab holds S*2*C DOUBLES (sums accumulated and combined in f64: E[x^2]-E[x]^2
+ * of an f32 tensor with |mean| >> std - the depthwise-conv outputs in front of decoder.py:131 - otherwise
+ * cancels 8-9 bits); allocate 2 * S*2*C floats.  The same holds for nvae_bn_stats_fin.             */
 int nvae_bn_stats(int dtype, const void* x, long rows, int C, float* partials, void* stream);
-/* mean/var from the slab; scale = gamma*invstd, shift = beta - mean*scale; moving stats updated
- * with Keras semantics: moving = moving*momentum + batch*(1-momentum).                          */
-int nvae_bn_finalize(const float* partials, long rows, int C, const float* gamma, const float* beta,
+/* mean/var from the slab nvae_bn_stats(dtype, ...) wrote; scale = gamma*invstd, shift = beta -
+ * mean*scale; moving stats updated with Keras semantics: moving = moving*momentum + batch*(1-momentum). */
+int nvae_bn_finalize(int dtype, const float* partials, long rows, int C, const float* gamma, const float* beta,
                      float* running_mean, float* running_var, float momentum, float eps,
                      float* scale, float* shift, float* mean, float* invstd, void* stream);
 /* as nvae_bn_finalize for a slab with an explicit number of row splits S (conv-epilogue statistics) */

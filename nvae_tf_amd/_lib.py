@@ -67,7 +67,7 @@ _SIGS = {
     "nvae_reduce_splits": None,
     "nvae_dwconv5_stats_rows": None,
     "nvae_bn_stats": [_i, _p, _l, _i, _p],
-    "nvae_bn_finalize": [_p, _l, _i, _p, _p, _p, _p, _f, _f, _p, _p, _p, _p],
+    "nvae_bn_finalize": [_i, _p, _l, _i, _p, _p, _p, _p, _f, _f, _p, _p, _p, _p],
     "nvae_bn_finalize_s": [_p, _i, _l, _i, _p, _p, _p, _p, _f, _f, _p, _p, _p, _p],
     "nvae_bn_eval_prepare": [_p, _p, _p, _p, _i, _f, _p, _p, _p, _p],
     "nvae_bn_apply": [_i, _p, _p, _l, _i, _p, _p, _i],

@@ -27,6 +27,7 @@ struct BnFinArgs {
     // backward (sum dpre, sum dpre*x -> dgamma, dbeta, k0, k1); reads scale/mean/invstd above
     float* dgamma; float* dbeta; float* k0k1;
     int frozen;
+    int slab_f64;                  // forward statistics slab holds doubles (k_stripreduce on f32 tensors, below)
 };
 
 // All threads of the workgroup call this after their partial stores.  Returns true (uniformly) in
@@ -97,6 +98,47 @@ __device__ __forceinline__ bool bn_slab_sum64(const float* partials, int S, int 
     return true;
 }
 
+// The same for a slab of DOUBLES.  The f32 activation path takes the statistics of tensors that no kernel
+// epilogue produces (notably the depthwise-conv outputs in front of bn3, decoder.py:131-132) from
+// k_stripreduce, and there E[x^2] - E[x]^2 in f32 is not good enough: |mean| / std reaches 15-19 on those
+// layers at initialisation, i.e. the subtraction cancels 8-9 bits, and through the ~330 layers of the C2
+// configuration that alone tripled the distance to the fp64 oracle (measured: the f32 oracle with this
+// single-pass variance is 3x further from fp64 than with a two-pass one).  Sums of x and x^2 accumulated and
+// combined in f64 make the single pass exact to f32 rounding of the inputs.
+__device__ __forceinline__ bool bn_slab_sum64_f64(const double* partials, int S, int C, int cbase, int& c,
+                                                  double& s1, double& s2) {
+    __shared__ double smd[4][2][64];
+    const int cl = threadIdx.x & 63, part = (threadIdx.x >> 6) & 3;
+    double a1 = 0.0, a2 = 0.0;
+    if (threadIdx.x < 256 && cbase + cl < C)
+        for (int s = part; s < S; s += 4) {
+            a1 += __hip_atomic_load(partials + ((long)s * 2) * C + cbase + cl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            a2 += __hip_atomic_load(partials + ((long)s * 2 + 1) * C + cbase + cl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    __syncthreads();
+    if (threadIdx.x < 256) { smd[part][0][cl] = a1; smd[part][1][cl] = a2; }
+    __syncthreads();
+    c = cbase + (int)threadIdx.x;
+    if (threadIdx.x >= 64 || c >= C) return false;
+    s1 = smd[0][0][cl] + smd[1][0][cl] + smd[2][0][cl] + smd[3][0][cl];
+    s2 = smd[0][1][cl] + smd[1][1][cl] + smd[2][1][cl] + smd[3][1][cl];
+    return true;
+}
+
+__device__ __forceinline__ void bn_fin_fwd_channel_f64(const BnFinArgs& a, int c, double s1, double s2) {
+    const double md = s1 * (double)a.inv_n;
+    const double vd = fmax(s2 * (double)a.inv_n - md * md, 0.0);
+    const float m = (float)md, var = (float)vd;
+    const float is = rsqrtf(var + a.eps);
+    const float sc = a.gamma[c] * is;
+    a.scale[c] = sc;
+    a.shift[c] = a.beta[c] - m * sc;
+    a.mean[c] = m;
+    a.invstd[c] = is;
+    a.rm[c] = a.rm[c] * a.momentum + m * (1.f - a.momentum);
+    a.rv[c] = a.rv[c] * a.momentum + var * (1.f - a.momentum);
+}
+
 __device__ __forceinline__ void bn_fin_fwd_channel(const BnFinArgs& a, int c, float s1, float s2) {
     const float m = s1 * a.inv_n;
     const float var = fmaxf(s2 * a.inv_n - m * m, 0.f);
@@ -126,8 +168,14 @@ __device__ __forceinline__ void bn_fin_bwd_channel(const BnFinArgs& a, int C, in
 __device__ __forceinline__ void bn_fin_fwd(const BnFinArgs& a, const float* partials, int S, int C,
                                            int cbase, int ngroups64) {
     for (int g = 0; g < ngroups64; ++g) {
-        int c; float s1, s2;
-        if (bn_slab_sum64(partials, S, C, cbase + g * 64, c, s1, s2)) bn_fin_fwd_channel(a, c, s1, s2);
+        int c;
+        if (a.slab_f64) {
+            double d1, d2;
+            if (bn_slab_sum64_f64((const double*)partials, S, C, cbase + g * 64, c, d1, d2)) bn_fin_fwd_channel_f64(a, c, d1, d2);
+        } else {
+            float s1, s2;
+            if (bn_slab_sum64(partials, S, C, cbase + g * 64, c, s1, s2)) bn_fin_fwd_channel(a, c, s1, s2);
+        }
     }
 }
 

@@ -18,11 +18,16 @@
 // MODE 2: per-image sum   q0 = x           (blockIdx.z = image, S = 1, direct store)
 // MODE 3: per-image sum   q0 = x*dy
 // MODE 4: column sum with leading dimension ld, q0 = x   (atomics, S small)
+// MODE 0 on f32 tensors accumulates and writes its slab in f64 (see bn_fin.h: bn_slab_sum64_f64)
+template <typename T, int MODE> struct StripAcc { typedef float type; };
+template <> struct StripAcc<float, 0> { typedef double type; };
+
 template <typename T, int MODE>
 __global__ __launch_bounds__(RED_THREADS) void k_stripreduce(
     const T* __restrict__ x, const T* __restrict__ dy, long rows_per_group, int C, int ld,
     int rows_per_block, const float* __restrict__ scale, const float* __restrict__ shift, int act,
     float* out, BnFinArgs fin) {
+    typedef typename StripAcc<T, MODE>::type A;
     constexpr int NQ = (MODE <= 1) ? 2 : 1;
     // thread groups of 8 channels per strip, padded to a power of two (1, 2, 4 or 8) so that lanes
     // holding the same channels are a fixed power-of-two apart
@@ -35,11 +40,11 @@ __global__ __launch_bounds__(RED_THREADS) void k_stripreduce(
     const long r0 = (long)blockIdx.y * rows_per_block;
     long r1 = r0 + rows_per_block;
     if (r1 > rows_per_group) r1 = rows_per_group;
-    float acc[NQ][8];
+    A acc[NQ][8];
 #pragma unroll
     for (int q = 0; q < NQ; ++q)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc[q][j] = 0.f;
+        for (int j = 0; j < 8; ++j) acc[q][j] = (A)0;
     float sc[8], sh[8];
     if (MODE == 1 && cval) {
 #pragma unroll
@@ -52,7 +57,7 @@ __global__ __launch_bounds__(RED_THREADS) void k_stripreduce(
             V8<T>::ld(x + off, v);
             if (MODE == 0) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) { acc[0][j] += v[j]; acc[1][j] += v[j] * v[j]; }
+                for (int j = 0; j < 8; ++j) { acc[0][j] += (A)v[j]; acc[1][j] += (A)v[j] * (A)v[j]; }
             } else if (MODE == 1) {
                 float g[8];
                 V8<T>::ld(dy + off, g);
@@ -79,11 +84,11 @@ __global__ __launch_bounds__(RED_THREADS) void k_stripreduce(
     for (int q = 0; q < NQ; ++q)
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            float v = acc[q][j];
+            A v = acc[q][j];
             for (int o = 32; o >= TGS; o >>= 1) v += __shfl_xor(v, o, 64);
             acc[q][j] = v;
         }
-    __shared__ float sm[4][8][NQ * 8];
+    __shared__ A sm[4][8][NQ * 8];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     if (lane < TGS) {
 #pragma unroll
@@ -97,10 +102,11 @@ __global__ __launch_bounds__(RED_THREADS) void k_stripreduce(
         for (int q = 0; q < NQ; ++q)
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                float v = sm[0][tg][q * 8 + j] + sm[1][tg][q * 8 + j] + sm[2][tg][q * 8 + j] + sm[3][tg][q * 8 + j];
-                if (MODE <= 1) bn_store_partial(out + ((long)blockIdx.y * NQ + q) * C + c0 + j, v);   // slab [S][NQ][C]
-                else if (MODE == 4) atomicAdd(out + c0 + j, v);
-                else out[grp * C + c0 + j] = v;                                       // [B][C], S == 1
+                A v = sm[0][tg][q * 8 + j] + sm[1][tg][q * 8 + j] + sm[2][tg][q * 8 + j] + sm[3][tg][q * 8 + j];
+                if (MODE <= 1) __hip_atomic_store((A*)out + ((long)blockIdx.y * NQ + q) * C + c0 + j, v, __ATOMIC_RELAXED,
+                                                  __HIP_MEMORY_SCOPE_AGENT);               // slab [S][NQ][C]
+                else if (MODE == 4) atomicAdd(out + c0 + j, (float)v);
+                else out[grp * C + c0 + j] = (float)v;                                // [B][C], S == 1
             }
     }
     if (MODE <= 1) {
@@ -156,12 +162,21 @@ extern "C" int nvae_bn_stats(int dtype, const void* x, long rows, int C, float* 
 __global__ void k_bn_finalize(const float* __restrict__ partials, int S, float inv_n, int C,
                               const float* __restrict__ gamma, const float* __restrict__ beta,
                               float* rm, float* rv, float momentum, float eps, float* scale,
-                              float* shift, float* mean, float* invstd) {
+                              float* shift, float* mean, float* invstd, int slab_f64) {
     int c;
-    float s1, s2;
-    if (!bn_slab_sum64(partials, S, C, blockIdx.x * 64, c, s1, s2)) return;
-    float m = s1 * inv_n;
-    float var = fmaxf(s2 * inv_n - m * m, 0.f);
+    float m, var;
+    if (slab_f64) {
+        double d1, d2;
+        if (!bn_slab_sum64_f64((const double*)partials, S, C, blockIdx.x * 64, c, d1, d2)) return;
+        const double md = d1 * (double)inv_n;
+        m = (float)md;
+        var = (float)fmax(d2 * (double)inv_n - md * md, 0.0);
+    } else {
+        float s1, s2;
+        if (!bn_slab_sum64(partials, S, C, blockIdx.x * 64, c, s1, s2)) return;
+        m = s1 * inv_n;
+        var = fmaxf(s2 * inv_n - m * m, 0.f);
+    }
     float is = rsqrtf(var + eps);
     float sc = gamma[c] * is;
     scale[c] = sc;
@@ -172,13 +187,13 @@ __global__ void k_bn_finalize(const float* __restrict__ partials, int S, float i
     rv[c] = rv[c] * momentum + var * (1.f - momentum);
 }
 
-extern "C" int nvae_bn_finalize(const float* partials, long rows, int C, const float* gamma,
+extern "C" int nvae_bn_finalize(int dtype, const float* partials, long rows, int C, const float* gamma,
                                 const float* beta, float* rm, float* rv, float momentum, float eps,
                                 float* scale, float* shift, float* mean, float* invstd, void* stream) {
     NVAE_REQUIRE(rows > 0 && C > 0, "bn_finalize: bad shape");
     const int S = nvae_reduce_splits(rows, C);
     hipLaunchKernelGGL(k_bn_finalize, cdiv(C, 64), 256, 0, (hipStream_t)stream, partials, S, 1.0f / (float)rows,
-                       C, gamma, beta, rm, rv, momentum, eps, scale, shift, mean, invstd);
+                       C, gamma, beta, rm, rv, momentum, eps, scale, shift, mean, invstd, dtype == NVAE_F32);
     NVAE_LAUNCH_CHECK("bn_finalize");
     return NVAE_OK;
 }
@@ -188,7 +203,7 @@ extern "C" int nvae_bn_finalize_s(const float* partials, int S, long rows, int C
                                   float* scale, float* shift, float* mean, float* invstd, void* stream) {
     NVAE_REQUIRE(rows > 0 && C > 0 && S > 0, "bn_finalize_s: bad shape");
     hipLaunchKernelGGL(k_bn_finalize, cdiv(C, 64), 256, 0, (hipStream_t)stream, partials, S, 1.0f / (float)rows,
-                       C, gamma, beta, rm, rv, momentum, eps, scale, shift, mean, invstd);
+                       C, gamma, beta, rm, rv, momentum, eps, scale, shift, mean, invstd, 0);
     NVAE_LAUNCH_CHECK("bn_finalize_s");
     return NVAE_OK;
 }
@@ -205,6 +220,7 @@ extern "C" int nvae_bn_stats_fin(int dtype, const void* x, long rows, int C, flo
     BnFinArgs f{};
     f.counter = counters; f.inv_n = 1.0f / (float)rows; f.gamma = gamma; f.beta = beta; f.rm = rm; f.rv = rv;
     f.momentum = momentum; f.eps = eps; f.scale = scale; f.shift = shift; f.mean = mean; f.invstd = invstd;
+    f.slab_f64 = dtype == NVAE_F32;
     DISPATCH_T(dtype, launch_strip<T, 0>((const T*)x, nullptr, 1, rows, C, C, S, nullptr, nullptr, 0, partials, (hipStream_t)stream, &f);)
     NVAE_LAUNCH_CHECK("bn_stats_fin");
     return NVAE_OK;

@@ -390,6 +390,11 @@ BN_MOMENTUM = 0.05   # Keras semantics: fraction of the OLD moving statistic kep
 BN_EPS = 1e-5
 
 
+def _stats_slab_dtype(ctx: Ctx) -> torch.dtype:
+    """Element type of the slab nvae_bn_stats / nvae_bn_stats_fin write: f64 on the f32 activation path."""
+    return torch.float64 if ctx.dtype == torch.float32 else torch.float32
+
+
 def bn_act(ctx: Ctx, x: Var, bn, act: int = L.ACT_NONE, lazy: bool = False) -> Var:
     """BatchNormalization(momentum=0.05, epsilon=1e-5) (+ Swish).  lazy: the only consumer applies the
     coefficients itself (se_residual): compute the coefficient table only and hand out the INPUT tensor
@@ -411,7 +416,7 @@ def bn_act(ctx: Ctx, x: Var, bn, act: int = L.ACT_NONE, lazy: bool = False) -> V
             call("nvae_bn_finalize_s", ptr(slab), Sx, rows, Cc, gamma, beta, rm, rv, BN_MOMENTUM, BN_EPS, scale,
                  shift, mean, invstd)
         elif ctx.training:
-            partials = ctx.empty((S, 2, Cc), torch.float32)
+            partials = ctx.empty((S, 2, Cc), _stats_slab_dtype(ctx))
             call("nvae_bn_stats_fin", ctx.dt, ptr(x.t), rows, Cc, ptr(partials), ctx.counters(), gamma, beta, rm,
                  rv, BN_MOMENTUM, BN_EPS, scale, shift, mean, invstd)
         else:
@@ -429,13 +434,13 @@ def bn_act(ctx: Ctx, x: Var, bn, act: int = L.ACT_NONE, lazy: bool = False) -> V
         call("nvae_bn_finalize_s", ptr(slab), Sx, rows, Cc, gamma, beta, rm, rv, BN_MOMENTUM, BN_EPS, scale,
              shift, mean, invstd)
     elif ctx.training:
-        partials = ctx.empty((S, 2, Cc), torch.float32)
+        partials = ctx.empty((S, 2, Cc), _stats_slab_dtype(ctx))
         if FUSED_FIN:
             call("nvae_bn_stats_fin", ctx.dt, ptr(x.t), rows, Cc, ptr(partials), ctx.counters(), gamma, beta, rm,
                  rv, BN_MOMENTUM, BN_EPS, scale, shift, mean, invstd)
         else:
             call("nvae_bn_stats", ctx.dt, ptr(x.t), rows, Cc, ptr(partials))
-            call("nvae_bn_finalize", ptr(partials), rows, Cc, gamma, beta, rm, rv, BN_MOMENTUM, BN_EPS, scale,
+            call("nvae_bn_finalize", ctx.dt, ptr(partials), rows, Cc, gamma, beta, rm, rv, BN_MOMENTUM, BN_EPS, scale,
                  shift, mean, invstd)
     else:
         call("nvae_bn_eval_prepare", gamma, beta, rm, rv, Cc, BN_EPS, scale, shift, mean, invstd)

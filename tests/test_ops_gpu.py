@@ -257,7 +257,7 @@ def test_bn_fused_finalize_matches_two_launch(lib, dev, shape):
                  ptr(counters), ptr(dg), ptr(db), ptr(k), 0)
         else:
             call("nvae_bn_stats", 1, ptr(x), rows, Cc, ptr(part))
-            call("nvae_bn_finalize", ptr(part), rows, Cc, ptr(gamma), ptr(beta), ptr(rm), ptr(rv), 0.05, 1e-5, sc,
+            call("nvae_bn_finalize", 1, ptr(part), rows, Cc, ptr(gamma), ptr(beta), ptr(rm), ptr(rv), 0.05, 1e-5, sc,
                  sh, mean, istd)
             call("nvae_bn_bwd_reduce", 1, ptr(x), ptr(dy), rows, Cc, sc, sh, 1, ptr(part))
             call("nvae_bn_bwd_finalize", ptr(part), rows, Cc, sc, mean, istd, ptr(dg), ptr(db), ptr(k), 0)
@@ -270,6 +270,40 @@ def test_bn_fused_finalize_matches_two_launch(lib, dev, shape):
         assert int(counters.abs().sum()) == 0
         for a, b in zip(got, ref):
             assert rel_err(a, b) < 1e-5
+
+
+@pytest.mark.parametrize("fused", [True, False], ids=["stats_fin", "stats+finalize"])
+def test_bn_stats_f32_survive_large_means(lib, dev, fused):
+    """f32 tensors whose channel means dwarf their spread (the depthwise-conv outputs in front of bn3 reach
+    |mean| / std = 15-19 at initialisation; here 200): the f32 strip reduce accumulates x and x^2 in f64, so the
+    single-pass variance keeps ~7 digits where f32 sums would keep 2-3."""
+    from nvae_tf_amd._lib import call, ptr
+    g = torch.Generator().manual_seed(11)
+    B, H, W_, Cc = 64, 4, 4, 192
+    rows = B * H * W_
+    x = (torch.randn(B, H, W_, Cc, generator=g) * 0.05 + torch.linspace(-10, 10, Cc)).float()
+    x64 = x.double()
+    mean_ref, var_ref = x64.mean((0, 1, 2)), x64.var((0, 1, 2), unbiased=False)
+    xd = x.to(dev)
+    S = lib.nvae_reduce_splits(rows, Cc)
+    part = torch.empty(S, 2, Cc, dtype=torch.float64, device=dev)
+    gamma, beta = torch.ones(Cc, device=dev), torch.zeros(Cc, device=dev)
+    rm, rv = torch.zeros(Cc, device=dev), torch.ones(Cc, device=dev)
+    coef = torch.empty(4, Cc, device=dev)
+    sc, sh, mean, istd = (ptr(coef) + i * Cc * 4 for i in range(4))
+    if fused:
+        counters = torch.zeros(256, dtype=torch.int32, device=dev)
+        call("nvae_bn_stats_fin", 0, ptr(xd), rows, Cc, ptr(part), ptr(counters), ptr(gamma), ptr(beta), ptr(rm),
+             ptr(rv), 0.05, 1e-5, sc, sh, mean, istd)
+    else:
+        call("nvae_bn_stats", 0, ptr(xd), rows, Cc, ptr(part))
+        call("nvae_bn_finalize", 0, ptr(part), rows, Cc, ptr(gamma), ptr(beta), ptr(rm), ptr(rv), 0.05, 1e-5, sc, sh,
+             mean, istd)
+    torch.cuda.synchronize()
+    got_var = 1.0 / coef[3].double().cpu() ** 2 - 1e-5
+    assert float(((coef[2].double().cpu() - mean_ref).abs() / mean_ref.abs().clamp_min(1e-3)).max()) < 1e-6
+    assert float(((got_var - var_ref).abs() / var_ref).max()) < 1e-4        # f32 sums: ~(200^2) * 6e-8 = 2.4e-3
+    assert rel_err(rv, 0.05 + 0.95 * var_ref) < 1e-5
 
 
 FUSED_CHAIN_CASES = [
