@@ -75,6 +75,34 @@ int nvae_conv_gemm_mtiles(int dtype, const NvaeConvGeom* g);
 int nvae_conv_gemm(int dtype, const NvaeConvGeom* g, const void* src, const void* wT, int w_ld,
                    const float* bias, const void* residual, void* out, int out_f32, float* stats,
                    void* stream);
+/* nvae_conv_gemm for the conv -> BN -> act -> conv chains of every residual cell (encoder.py:91-103,
+ * decoder.py:125-136, preprocess.py:84-99, postprocess.py:71-108), so that each BatchNorm costs no launch:
+ *  pre (may be NULL): `src` is the INPUT of a BatchNorm(+Swish) whose coefficient table (scale, shift) is
+ *    final; the kernel applies act(scale*x + shift) to the gathered operand inside LDS (zero padding stays
+ *    zero).  act_out (may be NULL, needs a stride-1 'same' geometry): the activated tensor is also written
+ *    out, [pixels][act_ld], for the weight gradient of this conv (nvae_conv_wgrad*).  Needs div == 1 and
+ *    Cin <= nvae_conv_gemm_pre_max_cin(dtype, g).
+ *  fin (may be NULL, needs stats): the BatchNorm that FOLLOWS this conv is finalized in-kernel from the
+ *    statistics slab by the last M-tile of every N-tile column to arrive (NvaeBnFin, declared below with the
+ *    SE kernels; counter: >= nvae N-tiles ints, zero at rest).                                          */
+typedef struct NvaeConvPre {
+    const float* scale; const float* shift;
+    int act;
+    void* act_out; int act_ld;
+} NvaeConvPre;
+/* In-kernel BatchNorm finalize ("the last workgroup to arrive turns the statistics slab into coefficients",
+ * csrc/bn_fin.h): what BatchNormalization(momentum, epsilon) needs besides the slab.                  */
+typedef struct NvaeBnFin {
+    int* counter;               /* zero at rest (reset by the kernel); one int per 64-column tile group */
+    const float* gamma; const float* beta;
+    float* rm; float* rv;       /* moving statistics, updated with Keras momentum semantics (SURVEY Q2) */
+    float momentum, eps;
+    float* scale; float* shift; float* mean; float* invstd;     /* [C] each: outputs */
+} NvaeBnFin;
+int nvae_conv_gemm_ex(int dtype, const NvaeConvGeom* g, const void* src, const void* wT, int w_ld,
+                      const float* bias, const void* residual, void* out, int out_f32, float* stats,
+                      const NvaeConvPre* pre, const NvaeBnFin* fin, void* stream);
+int nvae_conv_gemm_pre_max_cin(int dtype, const NvaeConvGeom* g);
 /* nvae_conv_gemm used as the DATA GRADIENT of a conv whose input was y = act(BN(x)) (the BNSwishConv /
  * ConvBNSwish pairs, encoder.py:91-98, decoder.py:125-135, postprocess.py:84-107): `out` receives dy
  * as usual and the epilogue additionally reduces dpre = dy * act'(scale*x + shift) against the same
@@ -259,13 +287,6 @@ int nvae_se_bwd_apply(int dtype, const void* dy, const float* gate, const float*
  * outputs (the backward pass and nvae_se_wgrad_batched read them).
  * stats (may be NULL): [nvae_se_fused_rows(B)][2][C] statistics slab of y for the BatchNorm that follows;
  * fin (may be NULL): that BatchNorm's finalize done by the last workgroup to arrive (see NvaeBnFin).  */
-typedef struct NvaeBnFin {
-    int* counter;               /* >= 1 int, zero at rest (reset by the kernel) */
-    const float* gamma; const float* beta;
-    float* rm; float* rv;       /* moving statistics, updated with Keras momentum semantics (SURVEY Q2) */
-    float momentum, eps;
-    float* scale; float* shift; float* mean; float* invstd;     /* [C] each: outputs */
-} NvaeBnFin;
 int nvae_se_fused_rows(int B);
 int nvae_se_fused_fwd(int dtype, const void* x, const float* bn_scale, const float* bn_shift,
                       const void* skip, void* y, int B, int HW, int C, int Hd, const float* w1,

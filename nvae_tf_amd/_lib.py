@@ -40,6 +40,11 @@ class BnFin(C.Structure):        # NvaeBnFin
                 ("shift", C.c_void_p), ("mean", C.c_void_p), ("invstd", C.c_void_p)]
 
 
+class ConvPre(C.Structure):      # NvaeConvPre
+    _fields_ = [("scale", C.c_void_p), ("shift", C.c_void_p), ("act", C.c_int), ("act_out", C.c_void_p),
+                ("act_ld", C.c_int)]
+
+
 class ConvDesc(C.Structure):
     _fields_ = [("w_off", C.c_longlong), ("wf_off", C.c_longlong), ("wd_off", C.c_longlong),
                 ("u_off", C.c_int), ("t_off", C.c_int), ("K", C.c_int), ("Cout", C.c_int),
@@ -54,6 +59,8 @@ _G = C.POINTER(ConvGeom)
 _SIGS = {
     "nvae_conv_gemm_mtiles": None,
     "nvae_conv_gemm": [_i, _G, _p, _p, _i, _p, _p, _p, _i, _p],
+    "nvae_conv_gemm_ex": [_i, _G, _p, _p, _i, _p, _p, _p, _i, _p, _p, _p],
+    "nvae_conv_gemm_pre_max_cin": None,
     "nvae_conv_gemm_bnbwd": [_i, _p, _p, _p, _i, _p, _p, _p, _p],
     "nvae_conv_wgrad_scratch": None,
     "nvae_conv_wgrad": [_i, _G, _p, _p, _p, _i, _p, _p, _l],
@@ -147,6 +154,8 @@ def load():
     lib.nvae_dwconv5_stats_rows.argtypes = [_i, _i, _i, _i, _i]
     lib.nvae_conv_gemm_mtiles.restype = C.c_int
     lib.nvae_conv_gemm_mtiles.argtypes = [_i, _G]
+    lib.nvae_conv_gemm_pre_max_cin.restype = C.c_int
+    lib.nvae_conv_gemm_pre_max_cin.argtypes = [_i, _G]
     lib.nvae_conv_wgrad_scratch.restype = C.c_long
     lib.nvae_conv_wgrad_scratch.argtypes = [_i, _G]
     for name, sig in _SIGS.items():

@@ -48,12 +48,13 @@ class Rescaler:
         self.conv = ps.conv(name + ".conv", 3, in_channels, n_channels)
         self.mode = rescale_type
         self.feeds_bn = False      # set by the owner when the output goes straight into a BatchNorm
+        self.stats_bn = None       # ... and which one (finalized by the conv kernel)
         self.factor = scale_factor
 
     def __call__(self, ctx: Ctx, x: Var) -> Var:
         y = ops.bn_act(ctx, x, self.bn, L.ACT_SWISH)
         if self.mode == RescaleType.UP:
-            return ops.conv2d(ctx, y, self.conv, up=self.factor, want_stats=self.feeds_bn)
+            return ops.conv2d(ctx, y, self.conv, up=self.factor, want_stats=self.feeds_bn, stats_bn=self.stats_bn)
         return ops.conv2d(ctx, y, self.conv, stride=self.factor)
 
 

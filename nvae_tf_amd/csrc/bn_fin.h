@@ -53,6 +53,26 @@ __device__ __forceinline__ bool bn_last_arriver(int* counter, int contributors) 
     return s_last != 0;
 }
 
+// The same in two halves, for producers that have more stores to issue after their slab partials (the conv
+// epilogue: output tile): bn_arrive() right after the partial stores - only those are waited for, the ticket's
+// round trip then overlaps the remaining stores - and bn_was_last() at the very end of the kernel.
+__device__ __forceinline__ int bn_arrive(int* counter) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's partial stores have been written through
+    __syncthreads();
+    return threadIdx.x == 0 ? atomicAdd(counter, 1) : 0;   // meaningful in thread 0 only
+}
+__device__ __forceinline__ bool bn_was_last(int* counter, int ticket, int contributors) {
+    __shared__ int s_last2;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int last = ticket == contributors - 1;
+        if (last) atomicExch(counter, 0);
+        s_last2 = last;
+    }
+    __syncthreads();
+    return s_last2 != 0;
+}
+
 // Sum slabs for channels [cbase, cbase + 64) with a workgroup of >= 256 threads.  The strip's slab rows
 // (row = 2*s + q, 64 floats each) are read as 16-B agent-scope loads, 16 rows in flight per thread, so
 // up to 128 splits cost ONE memory round trip (the loop form of this sum took 8).
@@ -168,14 +188,17 @@ __device__ __forceinline__ void bn_fin_bwd_channel(const BnFinArgs& a, int C, in
 __device__ __forceinline__ void bn_fin_fwd(const BnFinArgs& a, const float* partials, int S, int C,
                                            int cbase, int ngroups64) {
     for (int g = 0; g < ngroups64; ++g) {
-        int c;
-        if (a.slab_f64) {
-            double d1, d2;
-            if (bn_slab_sum64_f64((const double*)partials, S, C, cbase + g * 64, c, d1, d2)) bn_fin_fwd_channel_f64(a, c, d1, d2);
-        } else {
-            float s1, s2;
-            if (bn_slab_sum64(partials, S, C, cbase + g * 64, c, s1, s2)) bn_fin_fwd_channel(a, c, s1, s2);
-        }
+        int c; float s1, s2;
+        if (bn_slab_sum64(partials, S, C, cbase + g * 64, c, s1, s2)) bn_fin_fwd_channel(a, c, s1, s2);
+    }
+}
+// the same for a slab of doubles (k_stripreduce on f32 tensors); a separate function so that kernels which never
+// see such a slab do not carry its LDS
+__device__ __forceinline__ void bn_fin_fwd_f64(const BnFinArgs& a, const double* partials, int S, int C,
+                                               int cbase, int ngroups64) {
+    for (int g = 0; g < ngroups64; ++g) {
+        int c; double d1, d2;
+        if (bn_slab_sum64_f64(partials, S, C, cbase + g * 64, c, d1, d2)) bn_fin_fwd_channel_f64(a, c, d1, d2);
     }
 }
 

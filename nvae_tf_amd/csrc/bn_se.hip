@@ -113,7 +113,8 @@ __global__ __launch_bounds__(RED_THREADS) void k_stripreduce(
         // fused finalize: the last of this strip's gridDim.y workgroups turns the slabs into coefficients
         if (fin.counter == nullptr) return;
         if (!bn_last_arriver(fin.counter + blockIdx.x, (int)gridDim.y)) return;
-        if (MODE == 0) bn_fin_fwd(fin, out, (int)gridDim.y, C, blockIdx.x * 64, 1);
+        if constexpr (MODE == 0 && sizeof(A) == 8) bn_fin_fwd_f64(fin, (const double*)out, (int)gridDim.y, C, blockIdx.x * 64, 1);
+        else if constexpr (MODE == 0) bn_fin_fwd(fin, out, (int)gridDim.y, C, blockIdx.x * 64, 1);
         else bn_fin_bwd(fin, out, (int)gridDim.y, C, blockIdx.x * 64, 1);
     }
 }

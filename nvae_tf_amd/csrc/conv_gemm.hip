@@ -37,11 +37,61 @@ struct ConvBnBwd {
     BnFinArgs fin;
 };
 
+// A-operand prologue (nvae_conv_gemm_ex): the source tensor is the INPUT of a BatchNorm(+Swish) whose
+// coefficient table is final; the gathered chunks are turned into act(scale*x + shift) inside LDS, after
+// their DMA has landed and before the workgroup's barrier, by the thread that issued the DMA (it knows
+// which chunks are padding and must stay zero).  The normalised activation never makes a round trip of its
+// own through HBM (round 1: one nvae_bn_apply_fin launch of 6-40 us in front of every conv).  act_out
+// (optional): the activated tensor is written once, by the one N-tile workgroup whose turn it is, for the
+// weight-gradient kernel of the same conv (which runs much later, on the side stream).
+#define PRE_MAXC 2048            // channels of the coefficient table in LDS (k_conv_gemm2)
+#define PRE_MAXC_HALO 512        // (k_conv_halo: 152 KB of its 160 KB are the ring)
+struct ConvPre {
+    const float* scale; const float* shift;
+    int act;
+    void* act_out; int act_ld;
+};
+
+template <typename T> __device__ __forceinline__ uint4 pre_chunk(uint4 raw, const float* sc, const float* sh, int act);
+template <> __device__ __forceinline__ uint4 pre_chunk<bf16>(uint4 raw, const float* sc, const float* sh, int act) {
+    float v[8];
+    v[0] = __uint_as_float(raw.x << 16); v[1] = __uint_as_float(raw.x & 0xffff0000u);
+    v[2] = __uint_as_float(raw.y << 16); v[3] = __uint_as_float(raw.y & 0xffff0000u);
+    v[4] = __uint_as_float(raw.z << 16); v[5] = __uint_as_float(raw.z & 0xffff0000u);
+    v[6] = __uint_as_float(raw.w << 16); v[7] = __uint_as_float(raw.w & 0xffff0000u);
+    const float4 s0 = *(const float4*)sc, s1 = *(const float4*)(sc + 4), h0 = *(const float4*)sh, h1 = *(const float4*)(sh + 4);
+    const float scv[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+    const float shv[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float p = v[j] * scv[j] + shv[j];
+        v[j] = act == ACT_SWISH ? swishf_(p) : p;
+    }
+    uint4 r;
+    r.x = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
+    r.y = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
+    r.z = (unsigned)f2bf(v[4]) | ((unsigned)f2bf(v[5]) << 16);
+    r.w = (unsigned)f2bf(v[6]) | ((unsigned)f2bf(v[7]) << 16);
+    return r;
+}
+template <> __device__ __forceinline__ uint4 pre_chunk<float>(uint4 raw, const float* sc, const float* sh, int act) {
+    float v[4] = {__uint_as_float(raw.x), __uint_as_float(raw.y), __uint_as_float(raw.z), __uint_as_float(raw.w)};
+    const float4 s0 = *(const float4*)sc, h0 = *(const float4*)sh;
+    const float scv[4] = {s0.x, s0.y, s0.z, s0.w}, shv[4] = {h0.x, h0.y, h0.z, h0.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float p = v[j] * scv[j] + shv[j];
+        v[j] = act == ACT_SWISH ? swishf_(p) : p;
+    }
+    return make_uint4(__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3]));
+}
+
 template <typename T, int BM, int BN, int WM, int WN, bool BNBWD, typename RowMap>
 __device__ __forceinline__ void conv_epilogue(f32x4 (&acc)[BM / WM / 16][BN / WN / 16], float* lds_f,
                                               const NvaeConvGeom& g, const float* __restrict__ bias,
                                               const T* residual, void* out, int out_f32, int bm, int bn,
-                                              float* stats, int vec_epi, RowMap row_m, const ConvBnBwd& be) {
+                                              float* stats, int vec_epi, RowMap row_m, const ConvBnBwd& be,
+                                              int* stats_counter, int& ticket) {
     constexpr int NT = WM * WN * 64;
     constexpr int MI = BM / WM / 16, NI = BN / WN / 16;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -80,9 +130,17 @@ __device__ __forceinline__ void conv_epilogue(f32x4 (&acc)[BM / WM / 16][BN / WN
             float s1 = 0.f, s2 = 0.f;
 #pragma unroll
             for (int w = 0; w < WM; ++w) { s1 += red[(w * BN + nl) * 2]; s2 += red[(w * BN + nl) * 2 + 1]; }
-            stats[((long)bm * 2) * N + n] = s1;
-            stats[((long)bm * 2 + 1) * N + n] = s2;
+            if (stats_counter) {
+                bn_store_partial(stats + ((long)bm * 2) * N + n, s1);
+                bn_store_partial(stats + ((long)bm * 2 + 1) * N + n, s2);
+            } else {
+                stats[((long)bm * 2) * N + n] = s1;
+                stats[((long)bm * 2 + 1) * N + n] = s2;
+            }
         }
+        // forward statistics with an in-kernel finalize: take the arrival ticket now (only the slab stores are
+        // waited for; the ticket's round trip overlaps the output stores below), look at it when the kernel ends
+        if (stats_counter) ticket = bn_arrive(stats_counter + bn);
     }
     // (b) output.  Vector path: each wave stages one 16-row slab of its tile in LDS (f32), then every
     //     lane stores 8 consecutive columns of one row (16 B bf16 / 32 B f32) - whole-line writes
@@ -249,12 +307,12 @@ __device__ __forceinline__ void conv_epilogue(f32x4 (&acc)[BM / WM / 16][BN / WN
 //   Out-of-image (padding) and out-of-range lanes read a 16-B zero buffer instead of being masked:
 //   LDS-DMA needs every lane to write its slot.
 // =========================================================================================
-template <typename T, int BM, int BN, int WM, int WN, int STAGES, int BKC, bool BNBWD>
+template <typename T, int BM, int BN, int WM, int WN, int STAGES, int BKC, bool BNBWD, bool PRE>
 __global__ __launch_bounds__(WM* WN * 64) void k_conv_gemm2(
     NvaeConvGeom g, const T* __restrict__ src, const T* __restrict__ wT, int w_ld,
     const float* __restrict__ bias, const T* residual, void* out, int out_f32, int M, int K, int n_tiles,
     int total_tiles, FastDiv fd_hw, FastDiv fd_w, const uint4* __restrict__ zeros, float* stats,
-    int vec_epi, ConvBnBwd be) {
+    int vec_epi, ConvBnBwd be, ConvPre pre, BnFinArgs sfin) {
     constexpr int NT = WM * WN * 64;
     constexpr int VE = Tr<T>::VE;
     constexpr int BKE = BKC * VE;                  // K elements per ring step (BKC 16-B chunks per row)
@@ -268,6 +326,7 @@ __global__ __launch_bounds__(WM* WN * 64) void k_conv_gemm2(
     static_assert(STAGES * STAGE * 16 >= WM * BN * 2 * 4, "stats scratch must fit in the ring");
     static_assert(STAGES >= 2 && STAGES <= 4, "ring depth");
     __shared__ uint4 lds[STAGES * STAGE];
+    __shared__ __attribute__((aligned(16))) float pre_tab[PRE ? 2 * PRE_MAXC : 4];   // [scale | shift] of the prologue
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -345,6 +404,12 @@ __global__ __launch_bounds__(WM* WN * 64) void k_conv_gemm2(
 #pragma unroll
         for (int j = 0; j < NI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    // prologue state: the (tap, channel) position of ring step t, which lags `issue` by STAGES-1 steps
+    int p_kh = kh, p_kw = kw, p_ci = ci, p_kabs = kabs;
+    if constexpr (PRE) {
+        for (int c = tid; c < g.Cin; c += NT) { pre_tab[c] = pre.scale[c]; pre_tab[PRE_MAXC + c] = pre.shift[c]; }
+        __syncthreads();
+    }
     const int nk = (K + BKE - 1) / BKE;
     const int fr = lane & 15, fq = lane >> 4;
     issue(0);
@@ -357,6 +422,29 @@ __global__ __launch_bounds__(WM* WN * 64) void k_conv_gemm2(
         if (STAGES >= 4 && younger >= 2) wait_vmcnt<2 * NLOAD>();
         else if (STAGES >= 3 && younger >= 1) wait_vmcnt<NLOAD>();
         else wait_vmcnt<0>();
+        if constexpr (PRE) {
+            // this thread's own A chunks of stage t are in LDS (its DMA, its vmcnt): normalise + activate them in
+            // place; padding / out-of-range chunks stay zero.  The barrier below publishes them with the rest.
+            const bool kval = p_kabs < K;
+            const bool my_turn = pre.act_out && (t % n_tiles) == bn && p_kh == g.pad_t && p_kw == g.pad_l;
+#pragma unroll
+            for (int i = 0; i < ACH; ++i) {
+                const int hc = hb[i] + p_kh, wc = wb[i] + p_kw;
+                if (mv[i] && kval && hc >= 0 && hc < hlim && wc >= 0 && wc < wlim) {
+                    uint4* slot = lds + cur * STAGE + tid + NT * i;
+                    const uint4 v = pre_chunk<T>(*slot, pre_tab + p_ci, pre_tab + PRE_MAXC + p_ci, pre.act);
+                    *slot = v;
+                    if (my_turn) *(uint4*)((T*)pre.act_out + (pb[i] + (long)hc * g.Win + wc) * pre.act_ld + p_ci) = v;
+                }
+            }
+            p_kabs += BKE;
+            p_ci += BKE;
+            while (p_ci >= g.Cin) {
+                p_ci -= g.Cin;
+                if (++p_kw == g.KW) { p_kw = 0; ++p_kh; }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         // refill the slot that was read in step t-1 with the tile of step t + STAGES - 1
@@ -383,8 +471,15 @@ __global__ __launch_bounds__(WM* WN * 64) void k_conv_gemm2(
         cur = cur == STAGES - 1 ? 0 : cur + 1;
     }
 
+    int ticket = 0;
     conv_epilogue<T, BM, BN, WM, WN, BNBWD>(acc, (float*)lds, g, bias, residual, out, out_f32, bm, bn, stats, vec_epi,
-                                            [&](int r) -> long { int m = bm * BM + r; return m < M ? (long)m : -1L; }, be);
+                                            [&](int r) -> long { int m = bm * BM + r; return m < M ? (long)m : -1L; }, be,
+                                            sfin.counter, ticket);
+    if constexpr (!BNBWD) {
+        // the last M-tile of this column of tiles turns the statistics slab into the next BatchNorm's coefficients
+        if (stats && sfin.counter && bn_was_last(sfin.counter + bn, ticket, be.m_tiles))
+            bn_fin_fwd(sfin, stats, be.m_tiles, N, bn * BN, (BN + 63) / 64);
+    }
 }
 
 // =========================================================================================
@@ -400,12 +495,12 @@ __global__ __launch_bounds__(WM* WN * 64) void k_conv_gemm2(
 //   Halo rows are [pixel][8 chunks], slot = chunk ^ (row & 7): conflict-free for the 16x16x32 operand
 //   read at ANY row offset (the tap shift moves the 16-row window by kh*20 + kw rows).
 // =========================================================================================
-template <typename T, int BN, int KS, int WM, bool BNBWD>
+template <typename T, int BN, int KS, int WM, bool BNBWD, bool PRE>
 __global__ __launch_bounds__(WM * 128) void k_conv_halo(
     NvaeConvGeom g, const T* __restrict__ src, const T* __restrict__ wT, int w_ld,
     const float* __restrict__ bias, const T* residual, void* out, int out_f32, int n_tiles, int total_tiles,
     int patches_w, int patches_per_img, const uint4* __restrict__ zeros, float* stats, int vec_epi,
-    ConvBnBwd be) {
+    ConvBnBwd be, ConvPre pre, BnFinArgs sfin) {
     constexpr int BM = 256, WN = 2, NT = WM * WN * 64;
     constexpr int VE = Tr<T>::VE;
     constexpr int CCH = 8 * VE;                       // channels per halo chunk (64 bf16 / 32 f32)
@@ -415,8 +510,9 @@ __global__ __launch_bounds__(WM * 128) void k_conv_halo(
     constexpr int B_CHUNKS = BN * 8, BCH = B_CHUNKS / NT;
     constexpr int MI = 16 / WM, NI = BN / WN / 16;    // a wave owns MI rows of the 16 x 16 patch
     constexpr int PAD = (KS - 1) / 2, TAPS = KS * KS;
-    static_assert(B_CHUNKS % NT == 0 && A_PASSES <= TAPS, "tile/thread mismatch");
+    static_assert(B_CHUNKS % NT == 0 && A_PASSES + 1 <= TAPS, "tile/thread mismatch");
     __shared__ uint4 lds[2 * A_CHUNKS + 2 * B_CHUNKS];
+    __shared__ __attribute__((aligned(16))) float pre_tab[PRE ? 2 * PRE_MAXC_HALO : 4];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -475,12 +571,45 @@ __global__ __launch_bounds__(WM * 128) void k_conv_halo(
     const int ncc = g.Cin / CCH;
     const int S = ncc * TAPS;
     const int fr = lane & 15, fq = lane >> 4;
+    // prologue (see ConvPre): pass i of halo chunk `pcc` (buffer pcc & 1) is normalised + activated in place by the
+    // thread that DMA'd it, after its wait and before a barrier; halo pixels outside the image stay zero
+    auto pre_pass = [&](int pcc, int i) {
+        if (NT * i + wave * 64 >= A_CHUNKS || apix[i] < 0) return;
+        uint4* slot = lds + (pcc & 1) * A_CHUNKS + NT * i + tid;
+        const int c0 = pcc * CCH + sc;
+        const uint4 v = pre_chunk<T>(*slot, pre_tab + c0, pre_tab + PRE_MAXC_HALO + c0, pre.act);
+        *slot = v;
+        if (pre.act_out && (pcc % n_tiles) == bn) {
+            // interior of the halo = the patch's own 16 x 16 pixels: each is written by exactly one N-tile
+            const int hrow = row0 + (NT / 8) * i;
+            const int hy = hrow / HP, hx = hrow - hy * HP;
+            if (hy >= PAD && hy < PAD + 16 && hx >= PAD && hx < PAD + 16)
+                *(uint4*)((T*)pre.act_out + (apix[i] / g.in_ld) * pre.act_ld + (long)pcc * CCH + sc) = v;
+        }
+    };
+    if constexpr (PRE) {
+        for (int c = tid; c < g.Cin; c += NT) { pre_tab[c] = pre.scale[c]; pre_tab[PRE_MAXC_HALO + c] = pre.shift[c]; }
+        __syncthreads();
+    }
 #pragma unroll
     for (int i = 0; i < A_PASSES; ++i) issue_a(0, 0, i);
     issue_b(0, 0, 0);
     int cc = 0, tap = 0;
     for (int s = 0; s < S; ++s) {
         wait_vmcnt<0>();
+        if constexpr (PRE) {
+            if (s == 0) {
+#pragma unroll
+                for (int i = 0; i < A_PASSES; ++i) pre_pass(0, i);
+            } else if (tap >= 1 && tap <= A_PASSES && cc + 1 < ncc) {
+                // the pass issued one step ago (tap - 1) for the NEXT chunk has landed; its buffer is not read
+                // before chunk cc + 1 starts
+#pragma unroll
+                for (int i = 0; i < A_PASSES; ++i)
+                    if (i == tap - 1) pre_pass(cc + 1, i);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         {   // prefetch: next weight tile, and one pass of the next chunk's halo
@@ -516,8 +645,14 @@ __global__ __launch_bounds__(WM * 128) void k_conv_halo(
         }
         if (++tap == TAPS) { tap = 0; ++cc; }
     }
+    int ticket = 0;
     conv_epilogue<T, BM, BN, WM, WN, BNBWD>(acc, (float*)lds, g, bias, residual, out, out_f32, bp, bn, stats, vec_epi,
-                                            [&](int r) -> long { return ((long)b * H + py0 + (r >> 4)) * W + px0 + (r & 15); }, be);
+                                            [&](int r) -> long { return ((long)b * H + py0 + (r >> 4)) * W + px0 + (r & 15); }, be,
+                                            sfin.counter, ticket);
+    if constexpr (!BNBWD) {
+        if (stats && sfin.counter && bn_was_last(sfin.counter + bn, ticket, be.m_tiles))
+            bn_fin_fwd(sfin, stats, be.m_tiles, N, bn * BN, (BN + 63) / 64);
+    }
 }
 
 #ifndef HALO_WM
@@ -549,9 +684,16 @@ static int conv_gemm_bm(int dtype, const NvaeConvGeom* g) {
 template <typename T>
 static int launch_conv_gemm(const NvaeConvGeom* g, const void* src, const void* wT, int w_ld,
                             const float* bias, const void* residual, void* out, int out_f32,
-                            float* stats, hipStream_t s, const ConvBnBwd* fuse = nullptr) {
+                            float* stats, hipStream_t s, const ConvBnBwd* fuse = nullptr,
+                            const ConvPre* prologue = nullptr, const BnFinArgs* stats_fin = nullptr) {
     ConvBnBwd be{};
     if (fuse) be = *fuse;
+    ConvPre pre{};
+    if (prologue) pre = *prologue;
+    BnFinArgs sfin{};
+    if (stats_fin) sfin = *stats_fin;
+    const bool use_pre = pre.scale != nullptr;
+    if (!fuse) be.m_tiles = cdiv((long)g->B * g->Hout * g->Wout, conv_gemm_bm(sizeof(T) == 2 ? NVAE_BF16 : NVAE_F32, g));
     const int M = g->B * g->Hout * g->Wout, K = g->KH * g->KW * g->Cin, N = g->Cout;
     FastDiv fd_hw = make_fastdiv((unsigned)(g->Hout * g->Wout)), fd_w = make_fastdiv((unsigned)g->Wout);
     const uint4* zeros = zero_page();
@@ -563,24 +705,28 @@ static int launch_conv_gemm(const NvaeConvGeom* g, const void* src, const void* 
     if (conv_halo_ok(sizeof(T) == 2 ? NVAE_BF16 : NVAE_F32, g)) {
         const int pw = g->Win / 16, ppi = (g->Hin / 16) * pw;
         const int mt = g->B * ppi, nt = cdiv(N, 192);
-#define LAUNCH_HALO(KS_, WM_, F_)                                                                         \
-        hipLaunchKernelGGL((k_conv_halo<T, 192, KS_, WM_, F_>), mt * nt, WM_ * 128, 0, s, *g, (const T*)src,   \
+        if (use_pre && g->Cin > PRE_MAXC_HALO) return 2;
+#define LAUNCH_HALO(KS_, WM_, F_, P_)                                                                     \
+        hipLaunchKernelGGL((k_conv_halo<T, 192, KS_, WM_, F_, P_>), mt * nt, WM_ * 128, 0, s, *g, (const T*)src, \
                            (const T*)wT, w_ld, bias, (const T*)residual, out, out_f32, nt, mt * nt, pw, ppi,  \
-                           zeros, stats, vec_epi, be);
-        if (g->KH == 5) { if (be.x) LAUNCH_HALO(5, HALO_WM, true) else LAUNCH_HALO(5, HALO_WM, false) }
-        else { if (be.x) LAUNCH_HALO(3, 4, true) else LAUNCH_HALO(3, 4, false) }
+                           zeros, stats, vec_epi, be, pre, sfin);
+        if (g->KH == 5) { if (be.x) LAUNCH_HALO(5, HALO_WM, true, false) else if (use_pre) LAUNCH_HALO(5, HALO_WM, false, true) else LAUNCH_HALO(5, HALO_WM, false, false) }
+        else { if (be.x) LAUNCH_HALO(3, 4, true, false) else if (use_pre) LAUNCH_HALO(3, 4, false, true) else LAUNCH_HALO(3, 4, false, false) }
 #undef LAUNCH_HALO
         return 0;
     }
-#define LAUNCH2F(BM_, BN_, WM_, WN_, ST_, BKC_, F_)                                                     \
+    if (use_pre && g->Cin > PRE_MAXC) return 2;
+#define LAUNCH2F(BM_, BN_, WM_, WN_, ST_, BKC_, F_, P_)                                                 \
     {                                                                                                   \
         int mt = cdiv(M, BM_), nt = cdiv(N, BN_);                                                       \
-        hipLaunchKernelGGL((k_conv_gemm2<T, BM_, BN_, WM_, WN_, ST_, BKC_, F_>), mt * nt, WM_ * WN_ * 64, 0, s, *g, \
+        hipLaunchKernelGGL((k_conv_gemm2<T, BM_, BN_, WM_, WN_, ST_, BKC_, F_, P_>), mt * nt, WM_ * WN_ * 64, 0, s, *g, \
                            (const T*)src, (const T*)wT, w_ld, bias, (const T*)residual, out, out_f32, M, \
-                           K, nt, mt * nt, fd_hw, fd_w, zeros, stats, vec_epi, be);                     \
+                           K, nt, mt * nt, fd_hw, fd_w, zeros, stats, vec_epi, be, pre, sfin);          \
     }
 #define LAUNCH2(BM_, BN_, WM_, WN_, ST_, BKC_)                                                          \
-    { if (be.x) LAUNCH2F(BM_, BN_, WM_, WN_, ST_, BKC_, true) else LAUNCH2F(BM_, BN_, WM_, WN_, ST_, BKC_, false) }
+    { if (be.x) LAUNCH2F(BM_, BN_, WM_, WN_, ST_, BKC_, true, false)                                    \
+      else if (use_pre) LAUNCH2F(BM_, BN_, WM_, WN_, ST_, BKC_, false, true)                            \
+      else LAUNCH2F(BM_, BN_, WM_, WN_, ST_, BKC_, false, false) }
     // Large problems: 128-row tiles, 8 waves; N tile with the least padding (ties -> larger).
     // Small problems (few tiles): 64 x 64 tiles, 4 waves, so that the grid covers the chip.
     const long big_tiles = (long)cdiv(M, 128) * cdiv(N, 128);
@@ -627,6 +773,54 @@ extern "C" int nvae_conv_gemm(int dtype, const NvaeConvGeom* g, const void* src,
     return NVAE_OK;
 }
 
+
+// nvae_conv_gemm with (a) the BatchNorm(+Swish) in FRONT of the conv applied to the gathered operand inside the
+// kernel (ConvPre) and (b) the BatchNorm BEHIND it finalized by the last workgroups to arrive (fin): with both, a
+// conv -> BN -> act -> conv chain is one launch per conv and the normalised activations never touch HBM on their own.
+extern "C" int nvae_conv_gemm_ex(int dtype, const NvaeConvGeom* g, const void* src, const void* wT, int w_ld,
+                                 const float* bias, const void* residual, void* out, int out_f32, float* stats,
+                                 const NvaeConvPre* pre, const NvaeBnFin* fin, void* stream) {
+    if (int e = check_geom_mfma("conv_gemm_ex", g)) return e;
+    NVAE_REQUIRE(src && wT && out, "conv_gemm_ex: NULL pointer");
+    const int ve = (dtype == NVAE_BF16) ? 8 : 4;
+    NVAE_REQUIRE(g->Cin % ve == 0 && g->in_ld % ve == 0 && w_ld % ve == 0,
+                 "conv_gemm_ex: Cin=%d in_ld=%d w_ld=%d must be multiples of %d (use nvae_conv_direct)", g->Cin, g->in_ld, w_ld, ve);
+    NVAE_REQUIRE(w_ld >= g->KH * g->KW * g->Cin, "conv_gemm_ex: w_ld too small");
+    NVAE_REQUIRE(aligned16(src) && aligned16(wT), "conv_gemm_ex: src/wT must be 16-B aligned");
+    NVAE_REQUIRE(!residual || g->res_ld >= g->Cout, "conv_gemm_ex: res_ld too small");
+    ConvPre p{};
+    if (pre) {
+        NVAE_REQUIRE(pre->scale && pre->shift && aligned16(pre->scale) && aligned16(pre->shift),
+                     "conv_gemm_ex: prologue needs 16-B aligned scale / shift tables");
+        NVAE_REQUIRE(pre->act == ACT_NONE || pre->act == ACT_SWISH, "conv_gemm_ex: prologue act %d unsupported", pre->act);
+        NVAE_REQUIRE(g->div == 1, "conv_gemm_ex: the prologue does not combine with an upsampled / dilated gather");
+        NVAE_REQUIRE(!pre->act_out || (g->stride == 1 && g->Hin == g->Hout && g->Win == g->Wout && g->pad_t >= 0 &&
+                                       g->pad_t < g->KH && g->pad_l >= 0 && g->pad_l < g->KW && aligned16(pre->act_out) &&
+                                       pre->act_ld % ve == 0 && pre->act_ld >= g->Cin),
+                     "conv_gemm_ex: act_out needs a stride-1 'same' geometry (every source pixel is some output's centre tap)");
+        p.scale = pre->scale; p.shift = pre->shift; p.act = pre->act; p.act_out = pre->act_out; p.act_ld = pre->act_ld;
+    }
+    BnFinArgs f{};
+    if (fin) {
+        NVAE_REQUIRE(stats && fin->counter && fin->gamma && fin->beta && fin->rm && fin->rv && fin->scale && fin->shift &&
+                     fin->mean && fin->invstd, "conv_gemm_ex: in-kernel finalize needs the slab and every NvaeBnFin field");
+        f.counter = fin->counter; f.inv_n = 1.0f / (float)((long)g->B * g->Hout * g->Wout); f.gamma = fin->gamma;
+        f.beta = fin->beta; f.rm = fin->rm; f.rv = fin->rv; f.momentum = fin->momentum; f.eps = fin->eps;
+        f.scale = fin->scale; f.shift = fin->shift; f.mean = fin->mean; f.invstd = fin->invstd;
+    }
+    int rc = 0;
+    DISPATCH_T(dtype, rc = launch_conv_gemm<T>(g, src, wT, w_ld, bias, residual, out, out_f32, stats, (hipStream_t)stream,
+                                               nullptr, pre ? &p : nullptr, fin ? &f : nullptr);)
+    NVAE_REQUIRE(rc == 0, "conv_gemm_ex: Cin=%d exceeds the prologue's coefficient table for this tile family", g->Cin);
+    NVAE_LAUNCH_CHECK("conv_gemm_ex");
+    return NVAE_OK;
+}
+
+// Largest Cin the prologue of nvae_conv_gemm_ex takes for this geometry (0: unsupported geometry).
+extern "C" int nvae_conv_gemm_pre_max_cin(int dtype, const NvaeConvGeom* g) {
+    if (!g || g->div != 1) return 0;
+    return conv_halo_ok(dtype, g) ? PRE_MAXC_HALO : PRE_MAXC;
+}
 
 // nvae_conv_gemm for a data gradient whose destination feeds a BatchNorm backward: see ConvBnBwd.
 extern "C" int nvae_conv_gemm_bnbwd(int dtype, const NvaeConvGeom* g, const void* src, const void* wT, int w_ld,

@@ -40,12 +40,12 @@ class GenerativeResidualCell:
 
     def __call__(self, ctx: Ctx, inputs: Var) -> Var:
         x = ops.bn_act(ctx, inputs, self.batch_norm1)
-        x = ops.conv2d(ctx, x, self.conv1, want_stats=True)
+        x = ops.conv2d(ctx, x, self.conv1, stats_bn=self.batch_norm2)
         x = ops.bn_act(ctx, x, self.batch_norm2, L.ACT_SWISH)
         x = ops.dwconv5(ctx, x, self.depth_conv, want_stats=True)   # feeds bn3
         x = ops.bn_act(ctx, x, self.batch_norm3, L.ACT_SWISH)
-        x = ops.conv2d(ctx, x, self.conv2, want_stats=True)
-        x = ops.bn_act(ctx, x, self.batch_norm4, lazy=True)       # applied inside the SE kernel
+        x = ops.conv2d(ctx, x, self.conv2, stats_bn=self.batch_norm4)
+        x = ops.bn_act(ctx, x, self.batch_norm4)       # applied inside the SE kernel
         return self.se(ctx, x, inputs, 0.1, 1.0)
 
 

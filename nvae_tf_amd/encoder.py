@@ -33,7 +33,7 @@ class EncodingResidualCell:
 
     def __call__(self, ctx: Ctx, inputs: Var) -> Var:
         x = ops.bn_act(ctx, inputs, self.batch_norm1, L.ACT_SWISH)
-        x = ops.conv2d(ctx, x, self.conv1, want_stats=True)
+        x = ops.conv2d(ctx, x, self.conv1, stats_bn=self.batch_norm2)
         x = ops.bn_act(ctx, x, self.batch_norm2, L.ACT_SWISH)
         x = ops.conv2d(ctx, x, self.conv2)
         return self.se(ctx, x, inputs, 0.1, 1.0)

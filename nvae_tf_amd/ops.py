@@ -21,30 +21,48 @@ def same_pad(in_size: int, k: int, s: int) -> Tuple[int, int]:
 
 
 class Var:
-    """An NHWC activation and (lazily) its gradient."""
-    __slots__ = ("t", "g", "needs_grad", "stats", "uses", "bn_src", "pre")
+    """An NHWC activation and (lazily) its gradient.
+
+    A Var returned by bn_act is LAZY: `raw` is the BatchNorm's input and `pre` (a LazyBN) knows the
+    coefficient table; consumers that can apply the BatchNorm themselves (conv2d's operand prologue, the fused
+    SE kernels) read `raw` + `pre.coef()`, everybody else reads `t`, which materialises the normalised
+    activation on first use (one apply launch, as in round 1)."""
+    __slots__ = ("_t", "g", "needs_grad", "stats", "uses", "bn_src", "pre", "fin")
 
     def __init__(self, t: torch.Tensor, needs_grad: bool = True):
-        self.t = t
+        self._t = t
         self.g: Optional[torch.Tensor] = None
         self.needs_grad = needs_grad
-        self.stats = None   # (slab [S,2,C] f32, S): BN statistics partials emitted by the producing conv
+        self.stats = None   # (slab [S,2,C] f32, S): BN statistics partials emitted by the producing kernel
+        self.fin = None     # (bn, coef [4,C]): the producing kernel also finalized THAT BatchNorm's coefficients
         self.uses = 0       # ops that consumed this activation (each will add to .g in backward)
         self.bn_src = None  # set by bn_act on its output: what a consumer's data-gradient kernel needs
         #                     to reduce the BatchNorm backward sums in its epilogue (nvae_conv_gemm_bnbwd)
-        self.pre = None     # lazy BatchNorm: the value is act(scale * t + shift) with pre = (scale, shift, act)
-        #                     device pointers; t is the BatchNorm's INPUT.  Only consumers that apply the
-        #                     coefficients themselves (se_residual) may be handed such a Var.
+        self.pre = None     # LazyBN: the value is act(scale * raw + shift)
+
+    @property
+    def t(self) -> torch.Tensor:
+        return self._t if self.pre is None else self.pre.materialize()
+
+    @t.setter
+    def t(self, value: torch.Tensor):
+        self._t = value
+
+    @property
+    def raw(self) -> torch.Tensor:
+        return self._t
 
     @property
     def shape(self):
-        return self.t.shape
+        return self._t.shape
 
 
 FUSED_FIN = os.environ.get("NVAE_BN_FUSED_FIN", "1") != "0"
 APPLY_FIN = os.environ.get("NVAE_BN_APPLY_FIN", "1") != "0"   # slab -> coefficients inside the apply kernels
 SE_STATS = os.environ.get("NVAE_SE_STATS", "1") != "0"         # BN statistics out of the SE + residual kernel
 SE_FUSED = os.environ.get("NVAE_SE_FUSED", "1") != "0"         # SE + residual (+ the BatchNorm in front) as one launch
+CONV_PRE = os.environ.get("NVAE_CONV_PRE", "1") != "0"         # BatchNorm(+Swish) applied in the consuming conv's operand prologue
+STATS_FIN = os.environ.get("NVAE_STATS_FIN", "1") != "0"       # producers finalize the next BatchNorm in-kernel (last arriver)
 FUSE_BN_BWD = os.environ.get("NVAE_BN_BWD_FUSE", "1") != "0"   # BN backward sums in the dgrad epilogue
 
 
@@ -96,7 +114,7 @@ class Ctx:
     def grad_of(self, v: Var) -> Tuple[torch.Tensor, int]:
         """Gradient buffer of v and whether the next writer must accumulate into it."""
         if v.g is None:
-            v.g = torch.empty(v.t.shape, dtype=self.dtype, device=self.dev)
+            v.g = torch.empty(v.shape, dtype=self.dtype, device=self.dev)
             return v.g, 0
         return v.g, 1
 
@@ -240,16 +258,20 @@ def _geom(B, Hin, Win, Cin, Hout, Wout, Cout, KH, KW, stride, pad_t, pad_l, div,
 def conv2d(ctx: Ctx, x: Var, conv, *, stride: int = 1, up: int = 1, pad: Optional[Tuple[int, int]] = None,
            out_hw: Optional[Tuple[int, int]] = None, c_off: int = 0, cin: Optional[int] = None,
            bias: bool = True, out: Optional[Var] = None, out_coff: int = 0, accumulate: bool = False,
-           residual: Optional[Var] = None, out_f32: bool = False, want_stats: bool = False) -> Var:
+           residual: Optional[Var] = None, out_f32: bool = False, want_stats: bool = False,
+           stats_bn=None) -> Var:
     """Conv2D(padding='same') (+ folded nearest upsample, + residual add).  `conv` is a
     params.ConvParam.  c_off/cin select a row slice of a 1x1 kernel (concat-free
     DecoderSampleCombiner, decoder.py:115-117); out/out_coff write a channel slice of an existing
-    tensor (concat-free SkipScaler, preprocess.py:65-74)."""
+    tensor (concat-free SkipScaler, preprocess.py:65-74).
+    want_stats / stats_bn: the output feeds a BatchNorm (stats_bn: that layer, finalized in-kernel).
+    A lazy x (bn_act) is normalised + activated in the kernel's operand prologue when the geometry allows."""
     ps = ctx.ps
     x.uses += 1
     if residual is not None:
         residual.uses += 1
-    B, H, W, Cx = x.t.shape
+    want_stats = want_stats or stats_bn is not None
+    B, H, W, Cx = x.shape
     k = conv.k
     cin = conv.cin if cin is None else cin
     assert cin <= Cx and (c_off == 0 and cin == conv.cin or k == 1)
@@ -277,20 +299,44 @@ def conv2d(ctx: Ctx, x: Var, conv, *, stride: int = 1, up: int = 1, pad: Optiona
     ve = ctx.ve
     g = _geom(B, H, W, cin, Ho, Wo, cout, k, k, stride, pad[0], pad[1], up, 0, Cx, Cy, res_ld)
     fwd_mfma = cin % ve == 0 and Cx % ve == 0 and c_off % ve == 0 and conv.wf_off >= 0
+    # operand prologue: x = act(BN(raw)) is applied inside the conv kernel (and, for the weight gradient, written
+    # out once by it) when the gather is not upsampled and covers every source pixel as some output's centre tap
+    lib = L.load()
+    use_pre = (CONV_PRE and fwd_mfma and x.pre is not None and x.pre.mat is None and up == 1 and cin == Cx and c_off == 0
+               and 0 < Cx <= lib.nvae_conv_gemm_pre_max_cin(ctx.dt, C.byref(g))
+               and (not ctx.record or (stride == 1 and (Ho, Wo) == (H, W) and 0 <= pad[0] < k and 0 <= pad[1] < k)))
+    x_act: Optional[torch.Tensor] = None      # the activated input as the backward pass will read it
     if fwd_mfma:
         wT = ptr(ps.wcopies) + (conv.wf_off + c_off) * ps.wcopies.element_size()
-        slab = None
+        slab, fin = None, None
         if want_stats and ctx.training and not accumulate and out_coff == 0 and Cy == cout:
             # the conv's epilogue emits the BatchNorm statistics of its output (consumed by bn_act)
-            S = L.load().nvae_conv_gemm_mtiles(ctx.dt, C.byref(g))
+            S = lib.nvae_conv_gemm_mtiles(ctx.dt, C.byref(g))
             slab = ctx.empty((S, 2, cout), torch.float32)
             out.stats = (slab, S)
-        call("nvae_conv_gemm", ctx.dt, C.byref(g), ptr(x.t), wT, conv.wf_ld, bias_ptr, res_ptr, out_ptr,
-             int(out_f32), ptr(slab))
+            if want_fin(ctx, stats_bn):
+                coef = ctx.empty((4, cout), torch.float32)
+                fin = C.byref(bn_fin_struct(ctx, stats_bn, coef))
+                out.fin = (stats_bn, coef)
+        if use_pre:
+            sc, sh = x.pre.coef()
+            if ctx.record:
+                x_act = ctx.empty(x.shape)
+            pre = L.ConvPre(sc, sh, x.pre.act, ptr(x_act), Cx)
+            call("nvae_conv_gemm_ex", ctx.dt, C.byref(g), ptr(x.raw), wT, conv.wf_ld, bias_ptr, res_ptr, out_ptr,
+                 int(out_f32), ptr(slab), C.byref(pre), fin)
+        elif fin is not None:
+            call("nvae_conv_gemm_ex", ctx.dt, C.byref(g), ptr(x.t), wT, conv.wf_ld, bias_ptr, res_ptr, out_ptr,
+                 int(out_f32), ptr(slab), None, fin)
+        else:
+            call("nvae_conv_gemm", ctx.dt, C.byref(g), ptr(x.t), wT, conv.wf_ld, bias_ptr, res_ptr, out_ptr,
+                 int(out_f32), ptr(slab))
     else:
         w = ptr(ps.view(conv.w)) + c_off * cout * 4
         call("nvae_conv_direct", ctx.dt, C.byref(g), ptr(x.t), w, conv.cin * cout, cout, 1, 0, bias_ptr,
              res_ptr, out_ptr, int(out_f32))
+    if x_act is None and ctx.record:
+        x_act = x.t
 
     if ctx.record:
         def bwd():
@@ -305,9 +351,9 @@ def conv2d(ctx: Ctx, x: Var, conv, *, stride: int = 1, up: int = 1, pad: Optiona
             w_mfma = (cin % ve == 0 and Cx % ve == 0 and cout % ve == 0 and Cy % ve == 0
                       and out_coff % ve == 0)
             if w_mfma:
-                ctx.defer_wgrad(gw, x.t, dy, dy_ptr, dw, cout, db)
+                ctx.defer_wgrad(gw, x_act, dy, dy_ptr, dw, cout, db)
             else:
-                ctx.side_launch(lambda: call("nvae_conv_direct_wgrad", ctx.dt, C.byref(gw), ptr(x.t), dy_ptr, dw,
+                ctx.side_launch(lambda: call("nvae_conv_direct_wgrad", ctx.dt, C.byref(gw), ptr(x_act), dy_ptr, dw,
                                              cout, db), dy)
             # ---- residual
             if residual is not None and residual.needs_grad:
@@ -363,19 +409,20 @@ def dwconv5(ctx: Ctx, x: Var, dw, want_stats: bool = False) -> Var:
     BatchNorm, let the kernel emit its statistics slab (bf16 path)."""
     ps = ctx.ps
     x.uses += 1
-    B, H, W, Cc = x.t.shape
-    y = Var(ctx.empty(x.t.shape))
+    B, H, W, Cc = x.shape
+    xt = x.t
+    y = Var(ctx.empty(x.shape))
     rows = L.load().nvae_dwconv5_stats_rows(ctx.dt, B, H, W, Cc) if (want_stats and ctx.training) else 0
     if rows > 0:
         slab = ctx.empty((rows, 2, Cc), torch.float32)
-        call("nvae_dwconv5_stats", ctx.dt, ptr(x.t), ptr(ps.view(dw.w)), ptr(ps.view(dw.b)), ptr(y.t), B, H, W, Cc,
+        call("nvae_dwconv5_stats", ctx.dt, ptr(xt), ptr(ps.view(dw.w)), ptr(ps.view(dw.b)), ptr(y.t), B, H, W, Cc,
              ptr(slab))
         y.stats = (slab, rows)
     else:
-        call("nvae_dwconv5", ctx.dt, ptr(x.t), ptr(ps.view(dw.w)), ptr(ps.view(dw.b)), ptr(y.t), B, H, W, Cc, 0, 0)
+        call("nvae_dwconv5", ctx.dt, ptr(xt), ptr(ps.view(dw.w)), ptr(ps.view(dw.b)), ptr(y.t), B, H, W, Cc, 0, 0)
     if ctx.record:
         def bwd():
-            ctx.side_launch(lambda: call("nvae_dwconv5_wgrad", ctx.dt, ptr(x.t), ptr(y.g), ptr(ps.grads) + dw.w.off * 4,
+            ctx.side_launch(lambda: call("nvae_dwconv5_wgrad", ctx.dt, ptr(xt), ptr(y.g), ptr(ps.grads) + dw.w.off * 4,
                                          ptr(ps.grads) + dw.b.off * 4, B, H, W, Cc), y.g)
             g, acc = ctx.grad_of(x)
             call("nvae_dwconv5", ctx.dt, ptr(y.g), ptr(ps.view(dw.w)), None, ptr(g), B, H, W, Cc, 1, acc)
@@ -395,63 +442,105 @@ def _stats_slab_dtype(ctx: Ctx) -> torch.dtype:
     return torch.float64 if ctx.dtype == torch.float32 else torch.float32
 
 
-def bn_act(ctx: Ctx, x: Var, bn, act: int = L.ACT_NONE, lazy: bool = False) -> Var:
-    """BatchNormalization(momentum=0.05, epsilon=1e-5) (+ Swish).  lazy: the only consumer applies the
-    coefficients itself (se_residual): compute the coefficient table only and hand out the INPUT tensor
-    tagged with it (Var.pre); the normalised activation is never materialised."""
+def bn_fin_struct(ctx: Ctx, bn, coef: torch.Tensor) -> "L.BnFin":
+    """NvaeBnFin for a producer kernel that finalizes BatchNorm `bn` in-kernel into `coef` [4, C]."""
+    ps = ctx.ps
+    Cc = bn.c
+    base = ptr(coef)
+    return L.BnFin(ctx.counters(), ptr(ps.view(bn.gamma)), ptr(ps.view(bn.beta)), ptr(ps.sview(bn.rm)),
+                   ptr(ps.sview(bn.rv)), BN_MOMENTUM, BN_EPS, base, base + Cc * 4, base + 2 * Cc * 4, base + 3 * Cc * 4)
+
+
+def want_fin(ctx: Ctx, stats_bn) -> bool:
+    return stats_bn is not None and ctx.training and STATS_FIN
+
+
+class LazyBN:
+    """A BatchNorm(+act) whose application is left to its consumer.  State: where the coefficient table stands
+    (`ready`), and the materialised activation if somebody asked for it."""
+
+    def __init__(self, ctx: Ctx, x: Var, bn, act: int, coef: torch.Tensor, ready: bool):
+        self.ctx, self.x, self.bn, self.act, self.coef_t, self.ready = ctx, x, bn, act, coef, ready
+        Cc = bn.c
+        base = ptr(coef)
+        self.scale, self.shift, self.mean, self.invstd = (base + i * Cc * 4 for i in range(4))
+        self.mat: Optional[torch.Tensor] = None
+
+    def _bn_args(self):
+        ps, bn = self.ctx.ps, self.bn
+        return ptr(ps.view(bn.gamma)), ptr(ps.view(bn.beta)), ptr(ps.sview(bn.rm)), ptr(ps.sview(bn.rv))
+
+    def coef(self) -> Tuple[int, int]:
+        """Device pointers (scale, shift) of the FINAL coefficient table (one finalize launch if the producer left
+        only a statistics slab)."""
+        if not self.ready:
+            slab, Sx = self.x.stats
+            B, H, W, Cc = self.x.shape
+            call("nvae_bn_finalize_s", ptr(slab), Sx, B * H * W, Cc, *self._bn_args(), BN_MOMENTUM, BN_EPS, self.scale,
+                 self.shift, self.mean, self.invstd)
+            self.ready = True
+        return self.scale, self.shift
+
+    def materialize(self) -> torch.Tensor:
+        if self.mat is None:
+            ctx, x = self.ctx, self.x
+            B, H, W, Cc = x.shape
+            rows = B * H * W
+            self.mat = ctx.empty(x.shape)
+            if not self.ready and APPLY_FIN:
+                # statistics slab from the producing kernel: finalize + apply in one launch
+                slab, Sx = x.stats
+                call("nvae_bn_apply_fin", ctx.dt, ptr(x.t), ptr(self.mat), rows, Cc, ptr(slab), Sx, *self._bn_args(),
+                     BN_MOMENTUM, BN_EPS, self.scale, self.shift, self.mean, self.invstd, self.act)
+                self.ready = True
+            else:
+                sc, sh = self.coef()
+                call("nvae_bn_apply", ctx.dt, ptr(x.t), ptr(self.mat), rows, Cc, sc, sh, self.act)
+        return self.mat
+
+
+def bn_act(ctx: Ctx, x: Var, bn, act: int = L.ACT_NONE, lazy: bool = True) -> Var:
+    """BatchNormalization(momentum=0.05, epsilon=1e-5) (+ Swish).  Returns a LAZY Var (see Var): this call only
+    makes sure the statistics exist; whether the normalised activation is ever written to memory is the
+    consumer's decision.  lazy=False materialises at once."""
     ps = ctx.ps
     x.uses += 1
-    B, H, W, Cc = x.t.shape
+    B, H, W, Cc = x.shape
     rows = B * H * W
-    coef = ctx.empty((4, Cc), torch.float32)   # scale, shift, mean, invstd
-    scale, shift, mean, invstd = (ptr(coef) + i * Cc * 4 for i in range(4))
     gamma, beta = ptr(ps.view(bn.gamma)), ptr(ps.view(bn.beta))
     rm, rv = ptr(ps.sview(bn.rm)), ptr(ps.sview(bn.rv))
     S = L.load().nvae_reduce_splits(rows, Cc)
-    y = None
-    lazy = lazy and SE_FUSED and act == L.ACT_NONE and Cc & (Cc - 1) == 0 and 8 <= Cc <= 2048
-    if lazy:
+    if ctx.training and x.fin is not None and x.fin[0] is bn:
+        coef, ready = x.fin[1], True                    # finalized by the kernel that produced x
+    else:
+        coef = ctx.empty((4, Cc), torch.float32)        # scale, shift, mean, invstd
+        scale, shift, mean, invstd = (ptr(coef) + i * Cc * 4 for i in range(4))
         if ctx.training and x.stats is not None:
-            slab, Sx = x.stats
-            call("nvae_bn_finalize_s", ptr(slab), Sx, rows, Cc, gamma, beta, rm, rv, BN_MOMENTUM, BN_EPS, scale,
-                 shift, mean, invstd)
+            ready = False                               # slab only: finalized by whoever needs the table first
         elif ctx.training:
             partials = ctx.empty((S, 2, Cc), _stats_slab_dtype(ctx))
-            call("nvae_bn_stats_fin", ctx.dt, ptr(x.t), rows, Cc, ptr(partials), ctx.counters(), gamma, beta, rm,
-                 rv, BN_MOMENTUM, BN_EPS, scale, shift, mean, invstd)
+            if FUSED_FIN:
+                call("nvae_bn_stats_fin", ctx.dt, ptr(x.t), rows, Cc, ptr(partials), ctx.counters(), gamma, beta, rm,
+                     rv, BN_MOMENTUM, BN_EPS, scale, shift, mean, invstd)
+            else:
+                call("nvae_bn_stats", ctx.dt, ptr(x.t), rows, Cc, ptr(partials))
+                call("nvae_bn_finalize", ctx.dt, ptr(partials), rows, Cc, gamma, beta, rm, rv, BN_MOMENTUM, BN_EPS,
+                     scale, shift, mean, invstd)
+            ready = True
         else:
             call("nvae_bn_eval_prepare", gamma, beta, rm, rv, Cc, BN_EPS, scale, shift, mean, invstd)
-        y = Var(x.t, x.needs_grad)
-        y.pre = (scale, shift, act, coef)
-    elif ctx.training and x.stats is not None and APPLY_FIN:
-        # statistics slab from the producing kernel: finalize + apply in one launch
-        slab, Sx = x.stats
-        y = Var(ctx.empty(x.t.shape), x.needs_grad)
-        call("nvae_bn_apply_fin", ctx.dt, ptr(x.t), ptr(y.t), rows, Cc, ptr(slab), Sx, gamma, beta, rm, rv,
-             BN_MOMENTUM, BN_EPS, scale, shift, mean, invstd, act)
-    elif ctx.training and x.stats is not None:
-        slab, Sx = x.stats
-        call("nvae_bn_finalize_s", ptr(slab), Sx, rows, Cc, gamma, beta, rm, rv, BN_MOMENTUM, BN_EPS, scale,
-             shift, mean, invstd)
-    elif ctx.training:
-        partials = ctx.empty((S, 2, Cc), _stats_slab_dtype(ctx))
-        if FUSED_FIN:
-            call("nvae_bn_stats_fin", ctx.dt, ptr(x.t), rows, Cc, ptr(partials), ctx.counters(), gamma, beta, rm,
-                 rv, BN_MOMENTUM, BN_EPS, scale, shift, mean, invstd)
-        else:
-            call("nvae_bn_stats", ctx.dt, ptr(x.t), rows, Cc, ptr(partials))
-            call("nvae_bn_finalize", ctx.dt, ptr(partials), rows, Cc, gamma, beta, rm, rv, BN_MOMENTUM, BN_EPS, scale,
-                 shift, mean, invstd)
-    else:
-        call("nvae_bn_eval_prepare", gamma, beta, rm, rv, Cc, BN_EPS, scale, shift, mean, invstd)
-    if y is None:
-        y = Var(ctx.empty(x.t.shape), x.needs_grad)
-        call("nvae_bn_apply", ctx.dt, ptr(x.t), ptr(y.t), rows, Cc, scale, shift, act)
+            ready = True
+    scale, shift, mean, invstd = (ptr(coef) + i * Cc * 4 for i in range(4))
+    xt = x.t                                            # the BatchNorm's input (materialised if x itself is lazy)
+    y = Var(xt, x.needs_grad)
+    y.pre = LazyBN(ctx, x, bn, act, coef, ready)
+    if not lazy:
+        y.pre.materialize()
     if ctx.record:
         frozen = 0 if ctx.training else 1      # tf_literal: backward through moving-statistics BN
         dgamma = ptr(ps.grads) + bn.gamma.off * 4
         dbeta = ptr(ps.grads) + bn.beta.off * 4
-        info = dict(x=x.t, act=act, frozen=frozen, scale=scale, shift=shift, mean=mean, invstd=invstd,
+        info = dict(x=xt, act=act, frozen=frozen, scale=scale, shift=shift, mean=mean, invstd=invstd,
                     dgamma=dgamma, dbeta=dbeta, fused=False, coef=coef)
         y.bn_src = info
 
@@ -459,7 +548,7 @@ def bn_act(ctx: Ctx, x: Var, bn, act: int = L.ACT_NONE, lazy: bool = False) -> V
             if info["fused"] and APPLY_FIN and x.needs_grad:
                 # the sums were produced by the consumer's backward kernel: finalize + apply in one launch
                 g, acc = ctx.grad_of(x)
-                call("nvae_bn_bwd_apply_fin", ctx.dt, ptr(x.t), ptr(y.g), ptr(g), rows, Cc, ptr(info["partials"]),
+                call("nvae_bn_bwd_apply_fin", ctx.dt, ptr(xt), ptr(y.g), ptr(g), rows, Cc, ptr(info["partials"]),
                      info["mtiles"], scale, shift, mean, invstd, dgamma, dbeta, act, frozen, acc)
                 return
             if info["fused"]:
@@ -467,21 +556,21 @@ def bn_act(ctx: Ctx, x: Var, bn, act: int = L.ACT_NONE, lazy: bool = False) -> V
                      dgamma, dbeta, ptr(info["k0k1"]), frozen)
                 if x.needs_grad:
                     g, acc = ctx.grad_of(x)
-                    call("nvae_bn_bwd_apply", ctx.dt, ptr(x.t), ptr(y.g), ptr(g), rows, Cc, scale, shift,
+                    call("nvae_bn_bwd_apply", ctx.dt, ptr(xt), ptr(y.g), ptr(g), rows, Cc, scale, shift,
                          ptr(info["k0k1"]), act, acc)
                 return
             part = ctx.empty((S, 2, Cc), torch.float32)
             k0k1 = ctx.empty((2, Cc), torch.float32)
             if FUSED_FIN:
-                call("nvae_bn_bwd_reduce_fin", ctx.dt, ptr(x.t), ptr(y.g), rows, Cc, scale, shift, mean, invstd,
+                call("nvae_bn_bwd_reduce_fin", ctx.dt, ptr(xt), ptr(y.g), rows, Cc, scale, shift, mean, invstd,
                      act, ptr(part), ctx.counters(), dgamma, dbeta, ptr(k0k1), frozen)
             else:
-                call("nvae_bn_bwd_reduce", ctx.dt, ptr(x.t), ptr(y.g), rows, Cc, scale, shift, act, ptr(part))
+                call("nvae_bn_bwd_reduce", ctx.dt, ptr(xt), ptr(y.g), rows, Cc, scale, shift, act, ptr(part))
                 call("nvae_bn_bwd_finalize", ptr(part), rows, Cc, scale, mean, invstd, dgamma, dbeta, ptr(k0k1),
                      frozen)
             if x.needs_grad:
                 g, acc = ctx.grad_of(x)
-                call("nvae_bn_bwd_apply", ctx.dt, ptr(x.t), ptr(y.g), ptr(g), rows, Cc, scale, shift,
+                call("nvae_bn_bwd_apply", ctx.dt, ptr(xt), ptr(y.g), ptr(g), rows, Cc, scale, shift,
                      ptr(k0k1), act, acc)
             _ = coef   # keep alive
         ctx.tape.append(bwd)
@@ -495,31 +584,40 @@ def _se_fused_ok(Cc: int, Hd: int) -> bool:
     return SE_FUSED and Cc & (Cc - 1) == 0 and 8 <= Cc <= 2048 and Hd <= 128
 
 
-def se_residual(ctx: Ctx, x: Var, se, skip: Var, skip_scale: float, branch_scale: float) -> Var:
+def se_residual(ctx: Ctx, x: Var, se, skip: Var, skip_scale: float, branch_scale: float, stats_bn=None) -> Var:
     """y = skip_scale*skip + branch_scale*SE(x)   (SURVEY Q3 for which side carries the 0.1).  x may be a lazy
-    BatchNorm output (Var.pre): the fused kernels apply its coefficients on the fly."""
+    BatchNorm output (Var.pre): the fused kernels apply its coefficients on the fly.  stats_bn: the BatchNorm
+    that consumes y, if the caller knows it (finalized in-kernel)."""
     ps = ctx.ps
     x.uses += 1
     skip.uses += 1
-    B, H, W, Cc = x.t.shape
+    B, H, W, Cc = x.shape
     HW, Hd = H * W, se.hidden
     pooled = ctx.empty((B, Cc), torch.float32)
     gate = ctx.empty((B, Cc), torch.float32)
     hidden = ctx.empty((B, Hd), torch.float32)
     w1, b1, w2, b2 = (ptr(ps.view(p)) for p in (se.w1, se.b1, se.w2, se.b2))
     fused = _se_fused_ok(Cc, Hd)
-    assert x.pre is None or fused, "a lazy BatchNorm output needs the fused SE kernels"
-    pre_scale, pre_shift, pre_act = (x.pre[0], x.pre[1], x.pre[2]) if x.pre is not None else (None, None, L.ACT_NONE)
-    y = Var(ctx.empty(x.t.shape))
+    lazy_in = fused and x.pre is not None and x.pre.act == L.ACT_NONE and x.pre.mat is None
+    if lazy_in:
+        pre_scale, pre_shift = x.pre.coef()
+        pre_act, xin_t = x.pre.act, x.raw
+    else:
+        pre_scale, pre_shift, pre_act, xin_t = None, None, L.ACT_NONE, x.t
+    y = Var(ctx.empty(x.shape))
     if fused:
         # pool + FC + gate + residual add (+ the BatchNorm in front, + the statistics of y) in ONE launch
-        slab = None
+        slab, fin = None, None
         if ctx.training and SE_STATS:
             S = L.load().nvae_se_fused_rows(B)
             slab = ctx.empty((S, 2, Cc), torch.float32)
             y.stats = (slab, S)
-        call("nvae_se_fused_fwd", ctx.dt, ptr(x.t), pre_scale, pre_shift, ptr(skip.t), ptr(y.t), B, HW, Cc, Hd,
-             w1, b1, w2, b2, skip_scale, branch_scale, ptr(pooled), ptr(gate), ptr(hidden), ptr(slab), None)
+            if want_fin(ctx, stats_bn):
+                coef = ctx.empty((4, Cc), torch.float32)
+                fin = C.byref(bn_fin_struct(ctx, stats_bn, coef))
+                y.fin = (stats_bn, coef)
+        call("nvae_se_fused_fwd", ctx.dt, ptr(xin_t), pre_scale, pre_shift, ptr(skip.t), ptr(y.t), B, HW, Cc, Hd,
+             w1, b1, w2, b2, skip_scale, branch_scale, ptr(pooled), ptr(gate), ptr(hidden), ptr(slab), fin)
     else:
         if Cc <= 2048:
             call("nvae_se_pool_gate", ctx.dt, ptr(x.t), B, HW, Cc, Hd, w1, b1, w2, b2, ptr(pooled), ptr(gate), ptr(hidden))
@@ -559,8 +657,8 @@ def se_residual(ctx: Ctx, x: Var, se, skip: Var, skip_scale: float, branch_scale
                     src["fused"] = True
                     part = ptr(src["partials"])
                     assert accx == 0
-                if x.pre is not None:
-                    xin, f_scale, f_shift, f_act = ptr(x.t), pre_scale, pre_shift, pre_act
+                if lazy_in:
+                    xin, f_scale, f_shift, f_act = ptr(xin_t), pre_scale, pre_shift, pre_act
                 elif fuse:
                     # materialised BatchNorm output: the sums need the BatchNorm's input and coefficients, and
                     # r = sum xs*dy is recomputed from them as well (one tensor read instead of two)

@@ -16,7 +16,7 @@ class ConvBNSwish:
         self.bn = ps.bn(name_bn, n_channels)
 
     def __call__(self, ctx: Ctx, x: Var) -> Var:
-        x = ops.conv2d(ctx, x, self.conv, bias=False, want_stats=True)
+        x = ops.conv2d(ctx, x, self.conv, bias=False, stats_bn=self.bn)
         return ops.bn_act(ctx, x, self.bn, L.ACT_SWISH)
 
 
@@ -29,6 +29,8 @@ class PostprocessNode:
         if self.up is not None:
             self.up.feeds_bn = True        # node path: Rescaler -> bn0
         self.bn0 = ps.bn(name + ".bn0", n_channels)
+        if self.up is not None:
+            self.up.stats_bn = self.bn0
         hidden = n_channels * expansion_ratio
         self.cbs1 = ConvBNSwish(ps, name + ".conv1", name + ".bn1", n_channels, hidden, 1)
         self.cbs5 = ConvBNSwish(ps, name + ".conv5", name + ".bn2", hidden, hidden, 5)
@@ -42,8 +44,8 @@ class PostprocessNode:
         x = ops.bn_act(ctx, x, self.bn0)
         x = self.cbs1(ctx, x)
         x = self.cbs5(ctx, x)
-        x = ops.conv2d(ctx, x, self.conv3, bias=False, want_stats=True)
-        x = ops.bn_act(ctx, x, self.bn3, lazy=True)       # applied inside the SE kernel
+        x = ops.conv2d(ctx, x, self.conv3, bias=False, stats_bn=self.bn3)
+        x = ops.bn_act(ctx, x, self.bn3)       # applied inside the SE kernel
         return self.se(ctx, x, skip, 1.0, 0.1)      # skip + 0.1 * sequence, postprocess.py:58
 
 

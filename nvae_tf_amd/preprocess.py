@@ -54,7 +54,8 @@ class BNSwishConv:
         y = x
         for i, (bn, conv) in enumerate(zip(self.bns, self.convs)):
             y = ops.bn_act(ctx, y, bn, L.ACT_SWISH)
-            y = ops.conv2d(ctx, y, conv, stride=self.stride if i == 0 else 1, want_stats=(i + 1 < len(self.convs)))
+            y = ops.conv2d(ctx, y, conv, stride=self.stride if i == 0 else 1,
+                           stats_bn=self.bns[i + 1] if i + 1 < len(self.convs) else None)
         skipped = x if self.skip is None else self.skip(ctx, x)
         return self.se(ctx, y, skipped, 1.0, 0.1)
 

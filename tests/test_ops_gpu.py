@@ -320,10 +320,14 @@ FUSED_CHAIN_CASES = [
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
 @pytest.mark.parametrize("case", FUSED_CHAIN_CASES, ids=lambda c: "B{B}_H{H}_{ci}-{cm}-{co}_k{k1}{k2}".format(**c))
-def test_fused_bn_chain(lib, dev, dtype, case):
-    """conv -> BN(+Swish) -> conv against torch autograd (fp64): exercises the statistics epilogue of the
-    first conv, the finalize-in-apply forward and backward passes and the BatchNorm-backward reduction in
-    the second conv's data-gradient epilogue, at every conv tile configuration."""
+@pytest.mark.parametrize("mode", ["prologue+fin", "prologue", "materialised"])
+def test_fused_bn_chain(lib, dev, dtype, case, mode):
+    """conv -> BN(+Swish) -> conv against torch autograd (fp64) at every conv tile configuration.
+    prologue+fin: the first conv's epilogue emits the statistics and its last workgroups finalize the BatchNorm
+    (nvae_conv_gemm_ex fin), the second conv normalises + activates its operand in LDS and writes the activated
+    tensor for its own weight gradient (nvae_conv_gemm_ex pre): no BatchNorm launch at all in the forward pass.
+    prologue: statistics slab only, one nvae_bn_finalize_s launch.  materialised: round-1 sequence
+    (finalize-in-apply pass).  Backward: BatchNorm sums in the second conv's data-gradient epilogue."""
     from nvae_tf_amd import ops
     from nvae_tf_amd.ops import Var
     from nvae_tf_amd.params import ParamStore
@@ -356,10 +360,12 @@ def test_fused_bn_chain(lib, dev, dtype, case):
     # ---- kernels
     ctx = make_ctx(ps, dtype)
     xv = Var(x.to(dev, dtype))
-    hv = ops.conv2d(ctx, xv, c1, bias=False, want_stats=True)
-    assert hv.stats is not None
-    av = ops.bn_act(ctx, hv, bn, 1)
+    hv = ops.conv2d(ctx, xv, c1, bias=False, want_stats=True, stats_bn=bn if mode == "prologue+fin" else None)
+    assert hv.stats is not None and (hv.fin is not None) == (mode == "prologue+fin")
+    av = ops.bn_act(ctx, hv, bn, 1, lazy=mode != "materialised")
+    assert (av.pre.mat is None) == (mode != "materialised")
     y = ops.conv2d(ctx, av, c2)
+    assert (av.pre.mat is None) == (mode != "materialised")     # the prologue path never materialised it
     y.g = dy.to(dev, dtype)
     assert av.bn_src is not None and av.uses == 1
     ctx.backward()
@@ -416,9 +422,9 @@ def test_fused_bn_se_chain(lib, dev, dtype, shape, lazy):
     ctx = make_ctx(ps, dtype)
     xv, sv = Var(x.to(dev, dtype)), Var(skip.to(dev, dtype))
     av = ops.bn_act(ctx, xv, bn1, 0, lazy=lazy)
-    assert (av.pre is not None) == really_lazy and (av.t is xv.t) == really_lazy
-    rv = ops.se_residual(ctx, av, se, sv, 0.1, 1.0)
-    assert rv.stats is not None
+    rv = ops.se_residual(ctx, av, se, sv, 0.1, 1.0, stats_bn=bn2 if lazy else None)
+    assert (av.pre.mat is None) == really_lazy
+    assert rv.stats is not None and (rv.fin is not None) == really_lazy
     y = ops.bn_act(ctx, rv, bn2, 1)
     y.g = dy.to(dev, dtype)
     ctx.backward()
