@@ -545,6 +545,7 @@ def bn_act(ctx: Ctx, x: Var, bn, act: int = L.ACT_NONE, lazy: bool = True) -> Va
         y.bn_src = info
 
         def bwd():
+            y.pre.coef()        # (a lazy output nobody consumed in the forward pass: finalize now)
             if info["fused"] and APPLY_FIN and x.needs_grad:
                 # the sums were produced by the consumer's backward kernel: finalize + apply in one launch
                 g, acc = ctx.grad_of(x)
