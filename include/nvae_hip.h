@@ -68,25 +68,37 @@ typedef struct NvaeConvGeom {
 /* MFMA implicit GEMM.  wT: [Cout][w_ld] (k contiguous, k = (kh*KW+kw)*Cin + c), element type
  * `dtype`.  bias (f32, may be NULL), residual (dtype, may be NULL; may alias out = accumulate).
  * Requires Cin, in_ld, w_ld multiples of 8 (bf16) / 4 (f32) and 16-B aligned src/wT.            */
-/* stats (f32, may be NULL): [nvae_conv_gemm_mtiles(g)][2][Cout] per-M-tile column sums and sums of
- * squares of the output (bias included) - the BatchNorm statistics slab of the layer that follows,
- * consumed by nvae_bn_finalize_s.                                                                */
-int nvae_conv_gemm_mtiles(int dtype, const NvaeConvGeom* g);
+/* stats (f32, may be NULL, ZEROED): [nvae_conv_gemm_stats_rows(g)][2][Cout] column sums and sums of squares
+ * of the output (bias included) - the BatchNorm statistics slab of the layer that follows, consumed by
+ * nvae_bn_finalize_s / nvae_bn_apply_fin.  M-tile i ADDS (f32 atomics) into row i % rows: at most 64 adders
+ * per address, so nobody waits and a consumer sums 1-8 rows (tools/mb_atomic.hip).                  */
+int nvae_conv_gemm_stats_rows(int dtype, const NvaeConvGeom* g);
 int nvae_conv_gemm(int dtype, const NvaeConvGeom* g, const void* src, const void* wT, int w_ld,
                    const float* bias, const void* residual, void* out, int out_f32, float* stats,
                    void* stream);
 /* nvae_conv_gemm for the conv -> BN -> act -> conv chains of every residual cell (encoder.py:91-103,
  * decoder.py:125-136, preprocess.py:84-99, postprocess.py:71-108), so that each BatchNorm costs no launch:
- *  pre (may be NULL): `src` is the INPUT of a BatchNorm(+Swish) whose coefficient table (scale, shift) is
- *    final; the kernel applies act(scale*x + shift) to the gathered operand inside LDS (zero padding stays
- *    zero).  act_out (may be NULL, needs a stride-1 'same' geometry): the activated tensor is also written
+ *  pre (may be NULL): `src` is the INPUT of a BatchNorm(+Swish) (NvaeBnIn: final coefficient table, or
+ *    the accumulated statistics slab, which the kernel then finishes itself); the kernel applies
+ *    act(scale*x + shift) to the gathered operand inside LDS (zero padding stays zero).  act_out (may be NULL, needs a stride-1 'same' geometry): the activated tensor is also written
  *    out, [pixels][act_ld], for the weight gradient of this conv (nvae_conv_wgrad*).  Needs div == 1 and
  *    Cin <= nvae_conv_gemm_pre_max_cin(dtype, g).
  *  fin (may be NULL, needs stats): the BatchNorm that FOLLOWS this conv is finalized in-kernel from the
  *    statistics slab by the last M-tile of every N-tile column to arrive (NvaeBnFin, declared below with the
  *    SE kernels; counter: >= nvae N-tiles ints, zero at rest).                                          */
+/* A BatchNorm applied by its consumer.  Either the coefficient table is final (slab == NULL; scale, shift
+ * are inputs), or the consumer finishes the statistics itself: slab [rows][2][C] as accumulated by the
+ * producer (rows = 1-8), and scale / shift / mean / invstd (for the backward pass) and the moving statistics
+ * rm / rv are OUTPUTS written by one workgroup of the consuming kernel.                                 */
+typedef struct NvaeBnIn {
+    const float* slab; int rows;
+    float momentum, eps;
+    const float* gamma; const float* beta;
+    float* rm; float* rv;
+    float* scale; float* shift; float* mean; float* invstd;
+} NvaeBnIn;
 typedef struct NvaeConvPre {
-    const float* scale; const float* shift;
+    NvaeBnIn bn;                /* the BatchNorm in front of the conv (over the B*Hin*Win source pixels) */
     int act;
     void* act_out; int act_ld;
 } NvaeConvPre;
@@ -111,7 +123,8 @@ int nvae_conv_gemm_pre_max_cin(int dtype, const NvaeConvGeom* g);
  * would, so only nvae_bn_bwd_apply remains for that layer.  Requires 16-B aligned output rows and
  * Cout % 8 == 0.  counters: >= ceil(Cout/64) ints, zero at rest (shared with nvae_bn_stats_fin); with
  * counters == NULL the kernel only writes the slab and the caller runs nvae_bn_bwd_finalize_s with
- * S = nvae_conv_gemm_mtiles (the faster arrangement: workgroups retire without waiting).          */
+ * S = nvae_conv_gemm_stats_rows (the faster arrangement: workgroups retire without waiting); the
+ * partials slab must be ZEROED (the M-tiles add into it).          */
 typedef struct NvaeBnBwdFuse {
     const void* x;          /* BN input [B*Hout*Wout, x_ld], activation dtype */
     int x_ld, act, frozen;
@@ -155,8 +168,9 @@ int nvae_colsum(int dtype, const void* x, long rows, int C, int ld, float* out, 
 int nvae_dwconv5(int dtype, const void* x, const float* w, const float* bias, void* y, int B, int H,
                  int W, int C, int flip, int accumulate, void* stream);
 /* forward pass that also emits the BatchNorm statistics of its output (decoder.py:130-131: the
- * depthwise conv feeds BN3): stats[rows][2][C], rows = nvae_dwconv5_stats_rows(...) (0 = unsupported for
- * this dtype: use nvae_bn_stats), consumed by nvae_bn_finalize_s.                                  */
+ * depthwise conv feeds BN3): stats[rows][2][C] (ZEROED; the workgroups add into it with atomics, <= 64
+ * adders per address), rows = nvae_dwconv5_stats_rows(...) (0 = unsupported for this dtype: use
+ * nvae_bn_stats), consumed by nvae_bn_finalize_s / nvae_bn_apply_fin.                              */
 int nvae_dwconv5_stats_rows(int dtype, int B, int H, int W, int C);
 int nvae_dwconv5_stats(int dtype, const void* x, const float* w, const float* bias, void* y, int B, int H,
                        int W, int C, float* stats, void* stream);
@@ -222,7 +236,7 @@ int nvae_bn_bwd_reduce_fin(int dtype, const void* x, const void* dy, long rows, 
                            const float* scale, const float* shift, const float* mean,
                            const float* invstd, int act, float* partials, int* counters,
                            float* dgamma, float* dbeta, float* k0k1, int frozen, void* stream);
-/* as nvae_bn_bwd_finalize for a slab with S row splits (S = nvae_conv_gemm_mtiles for the slab that
+/* as nvae_bn_bwd_finalize for a slab with S row splits (S = nvae_conv_gemm_stats_rows for the slab that
  * nvae_conv_gemm_bnbwd leaves when it is given no counters)                                        */
 int nvae_bn_bwd_finalize_s(const float* partials, int S, long rows, int C, const float* scale,
                            const float* mean, const float* invstd, float* dgamma, float* dbeta,
@@ -280,23 +294,22 @@ int nvae_se_bwd_apply(int dtype, const void* dy, const float* gate, const float*
 /* ---- SE + residual (+ the BatchNorm in front of it) as one launch per direction: se_fused.hip ------
  * The tail of every residual cell, y = skip_scale*skip + branch_scale * SE(xs), xs = BN(x)
  * (decoder.py:135-147 bn4 -> se -> 0.1*inputs + ., postprocess.py:84-88 + 58) or xs = x
- * (encoder.py:99-107, preprocess.py:100-107).  bn_scale / bn_shift: the BatchNorm's coefficient table
- * (xs = scale*x + shift; both NULL: no BatchNorm), so its output is never materialised.  A workgroup owns
- * whole images: pool, both FC layers, gate, residual add and the BatchNorm statistics of y are one pass.
+ * (encoder.py:99-107, preprocess.py:100-107).  A workgroup owns whole images: pool, both FC layers, gate,
+ * residual add and the BatchNorm statistics of y are one pass with one global round trip.
+ * bn (may be NULL: no BatchNorm): see NvaeBnIn - the BatchNorm's output is never materialised.
  * C: a power of two in [8, 2048].  pooled_sum [B,C] (sum over HW of xs), gate [B,C], hidden [B,Hd] are
  * outputs (the backward pass and nvae_se_wgrad_batched read them).
- * stats (may be NULL): [nvae_se_fused_rows(B)][2][C] statistics slab of y for the BatchNorm that follows;
- * fin (may be NULL): that BatchNorm's finalize done by the last workgroup to arrive (see NvaeBnFin).  */
+ * stats (may be NULL; ZEROED): [nvae_se_fused_rows(B)][2][C] statistics slab of y for the BatchNorm that
+ * follows (accumulated with atomics, <= 64 adders per address).                                        */
 int nvae_se_fused_rows(int B);
-int nvae_se_fused_fwd(int dtype, const void* x, const float* bn_scale, const float* bn_shift,
-                      const void* skip, void* y, int B, int HW, int C, int Hd, const float* w1,
-                      const float* b1, const float* w2, const float* b2, float skip_scale,
-                      float branch_scale, float* pooled_sum, float* gate, float* hidden, float* stats,
-                      const NvaeBnFin* fin, void* stream);
+int nvae_se_fused_fwd(int dtype, const void* x, const NvaeBnIn* bn, const void* skip, void* y, int B, int HW,
+                      int C, int Hd, const float* w1, const float* b1, const float* w2, const float* b2,
+                      float skip_scale, float branch_scale, float* pooled_sum, float* gate, float* hidden,
+                      float* stats, void* stream);
 /* Backward of the same block: dx (+)= d/dxs, dskip (+)= skip_scale*dy (dskip may be NULL), FC gradient
  * scratch [B*(C+Hd)] for nvae_se_wgrad_batched.  act: activation of the folded BatchNorm (none / swish).
- * partials (may be NULL; needs bn_scale and acc_dx == 0): dxs is final, so the BatchNorm-backward sums of
- * the folded layer are reduced in the same pass: partials[nvae_se_fused_rows(B)][2][C] for
+ * partials (may be NULL; needs bn_scale and acc_dx == 0; ZEROED): dxs is final, so the BatchNorm-backward
+ * sums of the folded layer are accumulated in the same pass: partials[nvae_se_fused_rows(B)][2][C] for
  * nvae_bn_bwd_apply_fin / nvae_bn_bwd_finalize_s.                                                    */
 int nvae_se_fused_bwd(int dtype, const void* x, const float* bn_scale, const float* bn_shift, int act,
                       const void* dy, const float* gate, const float* hidden, void* dx, void* dskip, int B,

@@ -40,9 +40,14 @@ class BnFin(C.Structure):        # NvaeBnFin
                 ("shift", C.c_void_p), ("mean", C.c_void_p), ("invstd", C.c_void_p)]
 
 
+class BnIn(C.Structure):         # NvaeBnIn
+    _fields_ = [("slab", C.c_void_p), ("rows", C.c_int), ("momentum", C.c_float), ("eps", C.c_float),
+                ("gamma", C.c_void_p), ("beta", C.c_void_p), ("rm", C.c_void_p), ("rv", C.c_void_p),
+                ("scale", C.c_void_p), ("shift", C.c_void_p), ("mean", C.c_void_p), ("invstd", C.c_void_p)]
+
+
 class ConvPre(C.Structure):      # NvaeConvPre
-    _fields_ = [("scale", C.c_void_p), ("shift", C.c_void_p), ("act", C.c_int), ("act_out", C.c_void_p),
-                ("act_ld", C.c_int)]
+    _fields_ = [("bn", BnIn), ("act", C.c_int), ("act_out", C.c_void_p), ("act_ld", C.c_int)]
 
 
 class ConvDesc(C.Structure):
@@ -57,7 +62,7 @@ _G = C.POINTER(ConvGeom)
 
 # name -> argtypes (the trailing stream argument is appended automatically)
 _SIGS = {
-    "nvae_conv_gemm_mtiles": None,
+    "nvae_conv_gemm_stats_rows": None,
     "nvae_conv_gemm": [_i, _G, _p, _p, _i, _p, _p, _p, _i, _p],
     "nvae_conv_gemm_ex": [_i, _G, _p, _p, _i, _p, _p, _p, _i, _p, _p, _p],
     "nvae_conv_gemm_pre_max_cin": None,
@@ -99,7 +104,7 @@ _SIGS = {
     "nvae_se_bwd_apply": [_i, _p, _p, _p, _p, _p, _i, _i, _i, _f, _f, _i, _i],
     "nvae_se_bwd_apply_bn": [_i, _p, _p, _p, _p, _p, _i, _i, _i, _f, _f, _i, _p, _p, _p, _i, _p],
     "nvae_se_fused_rows": None,
-    "nvae_se_fused_fwd": [_i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _f, _f, _p, _p, _p, _p, _p],
+    "nvae_se_fused_fwd": [_i, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _f, _f, _p, _p, _p, _p],
     "nvae_se_fused_bwd": [_i, _p, _p, _p, _i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _f, _f, _i, _i, _p, _p],
     "nvae_unary_fwd": [_i, _i, _p, _p, _l, _f, _f],
     "nvae_unary_bwd": [_i, _i, _p, _p, _p, _l, _i],
@@ -152,8 +157,8 @@ def load():
     lib.nvae_se_fused_rows.argtypes = [_i]
     lib.nvae_dwconv5_stats_rows.restype = C.c_int
     lib.nvae_dwconv5_stats_rows.argtypes = [_i, _i, _i, _i, _i]
-    lib.nvae_conv_gemm_mtiles.restype = C.c_int
-    lib.nvae_conv_gemm_mtiles.argtypes = [_i, _G]
+    lib.nvae_conv_gemm_stats_rows.restype = C.c_int
+    lib.nvae_conv_gemm_stats_rows.argtypes = [_i, _G]
     lib.nvae_conv_gemm_pre_max_cin.restype = C.c_int
     lib.nvae_conv_gemm_pre_max_cin.argtypes = [_i, _G]
     lib.nvae_conv_wgrad_scratch.restype = C.c_long

@@ -73,6 +73,33 @@ __device__ __forceinline__ bool bn_was_last(int* counter, int ticket, int contri
     return s_last2 != 0;
 }
 
+// Coefficients of ONE channel straight from an accumulated statistics slab ([rows][2][C], rows = 1-8: the producers
+// add into it with atomics).  Cheap enough for every consumer workgroup to do for the channels it touches, so
+// neither a finalize launch nor a last-arriver hand-off is needed; the workgroup the caller elects (`publish`)
+// also writes the table for the backward pass and updates the moving statistics.
+struct BnFromSlab {
+    const float* slab; int rows;         // nullptr: scale / shift below are already final (inputs)
+    float inv_n, eps, momentum;
+    const float* gamma; const float* beta;
+    float* rm; float* rv;
+    float* scale; float* shift; float* mean; float* invstd;
+};
+__device__ __forceinline__ void bn_coef(const BnFromSlab& a, int C, int c, bool publish, float& sc, float& sh) {
+    if (a.slab == nullptr) { sc = a.scale[c]; sh = a.shift[c]; return; }
+    float s1 = 0.f, s2 = 0.f;
+    for (int r = 0; r < a.rows; ++r) { s1 += a.slab[((long)r * 2) * C + c]; s2 += a.slab[((long)r * 2 + 1) * C + c]; }
+    const float m = s1 * a.inv_n;
+    const float var = fmaxf(s2 * a.inv_n - m * m, 0.f);
+    const float is = rsqrtf(var + a.eps);
+    sc = a.gamma[c] * is;
+    sh = a.beta[c] - m * sc;
+    if (publish) {
+        a.scale[c] = sc; a.shift[c] = sh; a.mean[c] = m; a.invstd[c] = is;
+        a.rm[c] = a.rm[c] * a.momentum + m * (1.f - a.momentum);
+        a.rv[c] = a.rv[c] * a.momentum + var * (1.f - a.momentum);
+    }
+}
+
 // Sum slabs for channels [cbase, cbase + 64) with a workgroup of >= 256 threads.  The strip's slab rows
 // (row = 2*s + q, 64 floats each) are read as 16-B agent-scope loads, 16 rows in flight per thread, so
 // up to 128 splits cost ONE memory round trip (the loop form of this sum took 8).

@@ -347,7 +347,7 @@ extern "C" int nvae_bn_bwd_reduce_fin(int dtype, const void* x, const void* dy, 
 }
 
 // as nvae_bn_bwd_finalize for a slab with an explicit number of row splits (the conv-epilogue slab of
-// nvae_conv_gemm_bnbwd: S = nvae_conv_gemm_mtiles)
+// nvae_conv_gemm_bnbwd: S = nvae_conv_gemm_stats_rows)
 extern "C" int nvae_bn_bwd_finalize_s(const float* partials, int S, long rows, int C, const float* scale,
                                       const float* mean, const float* invstd, float* dgamma, float* dbeta,
                                       float* k0k1, int frozen, void* stream) {

@@ -31,7 +31,7 @@
 // nvae_bn_bwd_reduce disappears; nvae_bn_bwd_apply follows as before.
 struct ConvBnBwd {
     const void* x;          // BN input, [M, x_ld] in the activation dtype; nullptr = no fusion
-    int x_ld, act, m_tiles;
+    int x_ld, act, m_tiles, rows;   // M-tiles of the launch; rows of the (zeroed) slab they accumulate into
     const float* scale; const float* shift;
     float* partials;
     BnFinArgs fin;
@@ -47,7 +47,8 @@ struct ConvBnBwd {
 #define PRE_MAXC 2048            // channels of the coefficient table in LDS (k_conv_gemm2)
 #define PRE_MAXC_HALO 512        // (k_conv_halo: 152 KB of its 160 KB are the ring)
 struct ConvPre {
-    const float* scale; const float* shift;
+    BnFromSlab bn;              // final coefficient table, or the statistics slab to finish in-kernel (bn_fin.h)
+    bool on;
     int act;
     void* act_out; int act_ld;
 };
@@ -130,13 +131,12 @@ __device__ __forceinline__ void conv_epilogue(f32x4 (&acc)[BM / WM / 16][BN / WN
             float s1 = 0.f, s2 = 0.f;
 #pragma unroll
             for (int w = 0; w < WM; ++w) { s1 += red[(w * BN + nl) * 2]; s2 += red[(w * BN + nl) * 2 + 1]; }
-            if (stats_counter) {
-                bn_store_partial(stats + ((long)bm * 2) * N + n, s1);
-                bn_store_partial(stats + ((long)bm * 2 + 1) * N + n, s2);
-            } else {
-                stats[((long)bm * 2) * N + n] = s1;
-                stats[((long)bm * 2 + 1) * N + n] = s2;
-            }
+            // M-tile bm adds into row bm % rows of the zeroed slab: at most 64 adders per address (measured on
+            // MI355X, tools/mb_atomic.hip: <= 64 same-address float adders cost < 0.6 us and nobody waits for them;
+            // 256 cost 7 us, 1024 26 us), and a consumer sums `rows` (1-8) rows instead of up to 512
+            const int row = bm % be.rows;
+            atomicAdd(stats + ((long)row * 2) * N + n, s1);
+            atomicAdd(stats + ((long)row * 2 + 1) * N + n, s2);
         }
         // forward statistics with an in-kernel finalize: take the arrival ticket now (only the slab stores are
         // waited for; the ticket's round trip overlaps the output stores below), look at it when the kernel ends
@@ -217,15 +217,16 @@ __device__ __forceinline__ void conv_epilogue(f32x4 (&acc)[BM / WM / 16][BN / WN
             if (n >= N) continue;
             float a1 = 0.f, a2 = 0.f;
             for (int w = 0; w < WM * RPP; ++w) { a1 += red[(w * BN + nl) * 2]; a2 += red[(w * BN + nl) * 2 + 1]; }
-            bn_store_partial(be.partials + ((long)bm * 2) * N + n, a1);
-            bn_store_partial(be.partials + ((long)bm * 2 + 1) * N + n, a2);
+            const int row = bm % be.rows;
+            atomicAdd(be.partials + ((long)row * 2) * N + n, a1);
+            atomicAdd(be.partials + ((long)row * 2 + 1) * N + n, a2);
         }
         // With a counter the last M-tile of this column of tiles finalizes in place.  That makes every
         // workgroup wait for its own output stores and an atomic round trip before it frees its LDS
         // (measured: +4..8 us on kernels of 15-25 us), so the host normally passes no counter and runs
         // nvae_bn_bwd_finalize_s on the slab instead.
         if (be.fin.counter && bn_last_arriver(be.fin.counter + bn, be.m_tiles))
-            bn_fin_bwd(be.fin, be.partials, be.m_tiles, N, bn * BN, (BN + 63) / 64);
+            bn_fin_bwd(be.fin, be.partials, be.rows, N, bn * BN, (BN + 63) / 64);
         return;
     }
     if (vec_epi) {
@@ -407,7 +408,7 @@ __global__ __launch_bounds__(WM* WN * 64) void k_conv_gemm2(
     // prologue state: the (tap, channel) position of ring step t, which lags `issue` by STAGES-1 steps
     int p_kh = kh, p_kw = kw, p_ci = ci, p_kabs = kabs;
     if constexpr (PRE) {
-        for (int c = tid; c < g.Cin; c += NT) { pre_tab[c] = pre.scale[c]; pre_tab[PRE_MAXC + c] = pre.shift[c]; }
+        for (int c = tid; c < g.Cin; c += NT) bn_coef(pre.bn, g.Cin, c, blockIdx.x == 0, pre_tab[c], pre_tab[PRE_MAXC + c]);
         __syncthreads();
     }
     const int nk = (K + BKE - 1) / BKE;
@@ -478,7 +479,7 @@ __global__ __launch_bounds__(WM* WN * 64) void k_conv_gemm2(
     if constexpr (!BNBWD) {
         // the last M-tile of this column of tiles turns the statistics slab into the next BatchNorm's coefficients
         if (stats && sfin.counter && bn_was_last(sfin.counter + bn, ticket, be.m_tiles))
-            bn_fin_fwd(sfin, stats, be.m_tiles, N, bn * BN, (BN + 63) / 64);
+            bn_fin_fwd(sfin, stats, be.rows, N, bn * BN, (BN + 63) / 64);
     }
 }
 
@@ -588,7 +589,7 @@ __global__ __launch_bounds__(WM * 128) void k_conv_halo(
         }
     };
     if constexpr (PRE) {
-        for (int c = tid; c < g.Cin; c += NT) { pre_tab[c] = pre.scale[c]; pre_tab[PRE_MAXC_HALO + c] = pre.shift[c]; }
+        for (int c = tid; c < g.Cin; c += NT) bn_coef(pre.bn, g.Cin, c, blockIdx.x == 0, pre_tab[c], pre_tab[PRE_MAXC_HALO + c]);
         __syncthreads();
     }
 #pragma unroll
@@ -651,14 +652,14 @@ __global__ __launch_bounds__(WM * 128) void k_conv_halo(
                                             sfin.counter, ticket);
     if constexpr (!BNBWD) {
         if (stats && sfin.counter && bn_was_last(sfin.counter + bn, ticket, be.m_tiles))
-            bn_fin_fwd(sfin, stats, be.m_tiles, N, bn * BN, (BN + 63) / 64);
+            bn_fin_fwd(sfin, stats, be.rows, N, bn * BN, (BN + 63) / 64);
     }
 }
 
 #ifndef HALO_WM
 #define HALO_WM 4      // waves along M of the halo kernel: 4 -> 8 waves of 64 x 96, 2 -> 4 waves of 128 x 96
 #endif
-// halo kernel eligibility (must agree between the launcher and nvae_conv_gemm_mtiles)
+// halo kernel eligibility (must agree between the launcher and nvae_conv_gemm_stats_rows)
 static bool conv_halo_ok(int dtype, const NvaeConvGeom* g) {
     const int cch = dtype == NVAE_BF16 ? 64 : 32;
     const int N = g->Cout;
@@ -692,8 +693,9 @@ static int launch_conv_gemm(const NvaeConvGeom* g, const void* src, const void* 
     if (prologue) pre = *prologue;
     BnFinArgs sfin{};
     if (stats_fin) sfin = *stats_fin;
-    const bool use_pre = pre.scale != nullptr;
-    if (!fuse) be.m_tiles = cdiv((long)g->B * g->Hout * g->Wout, conv_gemm_bm(sizeof(T) == 2 ? NVAE_BF16 : NVAE_F32, g));
+    const bool use_pre = pre.on;
+    be.m_tiles = cdiv((long)g->B * g->Hout * g->Wout, conv_gemm_bm(sizeof(T) == 2 ? NVAE_BF16 : NVAE_F32, g));
+    be.rows = cdiv(be.m_tiles, 64);
     const int M = g->B * g->Hout * g->Wout, K = g->KH * g->KW * g->Cin, N = g->Cout;
     FastDiv fd_hw = make_fastdiv((unsigned)(g->Hout * g->Wout)), fd_w = make_fastdiv((unsigned)g->Wout);
     const uint4* zeros = zero_page();
@@ -752,9 +754,9 @@ static int launch_conv_gemm(const NvaeConvGeom* g, const void* src, const void* 
     return 0;
 }
 
-extern "C" int nvae_conv_gemm_mtiles(int dtype, const NvaeConvGeom* g) {
+extern "C" int nvae_conv_gemm_stats_rows(int dtype, const NvaeConvGeom* g) {
     if (!g) return 0;
-    return cdiv((long)g->B * g->Hout * g->Wout, conv_gemm_bm(dtype, g));
+    return cdiv(cdiv((long)g->B * g->Hout * g->Wout, conv_gemm_bm(dtype, g)), 64);
 }
 
 extern "C" int nvae_conv_gemm(int dtype, const NvaeConvGeom* g, const void* src, const void* wT, int w_ld,
@@ -790,15 +792,24 @@ extern "C" int nvae_conv_gemm_ex(int dtype, const NvaeConvGeom* g, const void* s
     NVAE_REQUIRE(!residual || g->res_ld >= g->Cout, "conv_gemm_ex: res_ld too small");
     ConvPre p{};
     if (pre) {
-        NVAE_REQUIRE(pre->scale && pre->shift && aligned16(pre->scale) && aligned16(pre->shift),
-                     "conv_gemm_ex: prologue needs 16-B aligned scale / shift tables");
+        const NvaeBnIn* in = &pre->bn;
+        NVAE_REQUIRE(in->scale && in->shift, "conv_gemm_ex: prologue needs scale / shift");
+        p.on = true;
+        p.bn.scale = in->scale; p.bn.shift = in->shift; p.bn.mean = in->mean; p.bn.invstd = in->invstd;
+        if (in->slab) {
+            NVAE_REQUIRE(in->rows > 0 && in->gamma && in->beta && in->rm && in->rv && in->mean && in->invstd,
+                         "conv_gemm_ex: NvaeBnIn with a slab needs rows, gamma, beta, rm, rv, mean, invstd");
+            p.bn.slab = in->slab; p.bn.rows = in->rows; p.bn.inv_n = 1.0f / (float)((long)g->B * g->Hin * g->Win);
+            p.bn.eps = in->eps; p.bn.momentum = in->momentum; p.bn.gamma = in->gamma; p.bn.beta = in->beta;
+            p.bn.rm = in->rm; p.bn.rv = in->rv;
+        }
         NVAE_REQUIRE(pre->act == ACT_NONE || pre->act == ACT_SWISH, "conv_gemm_ex: prologue act %d unsupported", pre->act);
         NVAE_REQUIRE(g->div == 1, "conv_gemm_ex: the prologue does not combine with an upsampled / dilated gather");
         NVAE_REQUIRE(!pre->act_out || (g->stride == 1 && g->Hin == g->Hout && g->Win == g->Wout && g->pad_t >= 0 &&
                                        g->pad_t < g->KH && g->pad_l >= 0 && g->pad_l < g->KW && aligned16(pre->act_out) &&
                                        pre->act_ld % ve == 0 && pre->act_ld >= g->Cin),
                      "conv_gemm_ex: act_out needs a stride-1 'same' geometry (every source pixel is some output's centre tap)");
-        p.scale = pre->scale; p.shift = pre->shift; p.act = pre->act; p.act_out = pre->act_out; p.act_ld = pre->act_ld;
+        p.act = pre->act; p.act_out = pre->act_out; p.act_ld = pre->act_ld;
     }
     BnFinArgs f{};
     if (fin) {
@@ -841,7 +852,7 @@ extern "C" int nvae_conv_gemm_bnbwd(int dtype, const NvaeConvGeom* g, const void
                  "conv_gemm_bnbwd: Cout=%d / x_ld=%d must be multiples of 8 and x 16-B aligned", g->Cout, f->x_ld);
     NVAE_REQUIRE(f->act == ACT_NONE || f->act == ACT_SWISH, "conv_gemm_bnbwd: act %d unsupported", f->act);
     ConvBnBwd be{};
-    be.x = f->x; be.x_ld = f->x_ld; be.act = f->act; be.m_tiles = nvae_conv_gemm_mtiles(dtype, g);
+    be.x = f->x; be.x_ld = f->x_ld; be.act = f->act; 
     be.scale = f->scale; be.shift = f->shift; be.partials = f->partials;
     be.fin.counter = f->counters;
     be.fin.inv_n = 1.0f / (float)((long)g->B * g->Hout * g->Wout);

@@ -19,6 +19,7 @@
 #include "conv_common.h"      // glds16 (LDS-DMA), wait_vmcnt, zero_page
 
 #define DW_CC 64          // channels per workgroup
+__device__ __forceinline__ int cdiv_dev(int a, int b) { return (a + b - 1) / b; }
 
 template <typename T> struct DwVec;     // 4 channels <-> float[4]
 template <> struct DwVec<bf16> {
@@ -254,7 +255,7 @@ __global__ __launch_bounds__(256, 2) void k_dw5_fwd_ring(const bf16* __restrict_
         }
     }
     if (stats) {
-        // per-workgroup column sums -> stats[blockIdx.y][2][C] (the slab nvae_bn_finalize_s consumes)
+        // per-workgroup column sums, accumulated into the (zeroed) slab nvae_bn_finalize_s / nvae_bn_apply_fin consume
         st1.x += __shfl_xor(st1.x, 32, 64); st1.y += __shfl_xor(st1.y, 32, 64);
         st2.x += __shfl_xor(st2.x, 32, 64); st2.y += __shfl_xor(st2.y, 32, 64);
         __syncthreads();                 // the ring is dead: reuse it as [4 waves][32 pairs][4]
@@ -271,8 +272,10 @@ __global__ __launch_bounds__(256, 2) void k_dw5_fwd_ring(const bf16* __restrict_
                 float a1 = 0.f, a2 = 0.f;
 #pragma unroll
                 for (int wv = 0; wv < 4; ++wv) { a1 += red[(wv * 32 + pr) * 4 + e]; a2 += red[(wv * 32 + pr) * 4 + 2 + e]; }
-                stats[((long)blockIdx.y * 2) * C + cc] = a1;
-                stats[((long)blockIdx.y * 2 + 1) * C + cc] = a2;
+                // workgroup y adds into row y % rows of the zeroed slab (<= 64 adders per address, conv_gemm.hip)
+                const int row = blockIdx.y % cdiv_dev((int)gridDim.y, 64);
+                atomicAdd(stats + ((long)row * 2) * C + cc, a1);
+                atomicAdd(stats + ((long)row * 2 + 1) * C + cc, a2);
             }
         }
     }
@@ -290,7 +293,7 @@ static long dw_ring_rows(int B, int H, int W, int C) {
 
 extern "C" int nvae_dwconv5_stats_rows(int dtype, int B, int H, int W, int C) {
     if (dtype != NVAE_BF16 || B <= 0 || H <= 0 || W <= 0 || C < 8 || C % 8) return 0;
-    return (int)dw_ring_rows(B, H, W, C);
+    return cdiv(dw_ring_rows(B, H, W, C), 64);
 }
 
 static int dwconv5_impl(int dtype, const void* x, const float* w, const float* bias, void* y, int B, int H, int W,

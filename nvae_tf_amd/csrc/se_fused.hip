@@ -7,8 +7,14 @@
 // se_reduce_gate_bwd + se_bwd_apply_bn (backward): five launches of 6-11 us on 1-8 MB tensors, bound by
 // launch latency.  Here a workgroup owns whole images (all channels), so the pooling, the two FC layers,
 // the gate, the residual add AND the BatchNorm statistics of y (the next cell starts with a BatchNorm) are
-// one pass; the BatchNorm in front is applied on the fly from its coefficient table (its output is never
-// materialised; the average pool of an affine map is the affine map of the pool).
+// one pass; the BatchNorm in front is applied on the fly - from its coefficient table, or straight from the
+// statistics slab its producer accumulated (bn_fin.h BnFromSlab: no finalize launch either); its output is
+// never materialised (the average pool of an affine map is the affine map of the pool).
+//
+// Latency: these tensors are 1-8 MB, so the kernel is as long as its chain of dependent memory round trips.
+// Everything it needs (the image's x and skip chunks, both FC matrices, the slab) is requested in the first
+// instructions, so there is ONE global round trip before the stores; images of up to NCH * RL pixels stay in
+// registers between the pooling pass and the apply pass.
 //
 // Thread layout: CG = C/8 channel groups (power of two <= 256), RL = 256/CG row lanes; thread (rl, tg)
 // owns channels [8 tg, 8 tg + 8) of pixels rl, rl + RL, ...: 16-B loads, whole 128-B lines per wave.
@@ -17,11 +23,7 @@
 
 #define SEF_MAX_C 2048
 #define SEF_MAX_H 128
-
-__device__ __forceinline__ void sef_ld8(const float* p, float (&v)[8]) {
-    const float4 a = *(const float4*)p, b = *(const float4*)(p + 4);
-    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
-}
+#define SEF_W_LDS 4096          // FC matrices of up to this many floats each are staged in LDS
 
 // cross-row-lane reduction of NQ per-thread 8-vectors: part is [NQ][RL][C] = NQ * 2048 floats
 template <int NQ>
@@ -37,54 +39,93 @@ __device__ __forceinline__ float sef_gather(const float* part, int q, int c, int
     return v;
 }
 
-template <typename T>
+struct SefOut {                 // statistics of y for the BatchNorm that follows: rows of a ZEROED slab
+    float* stats; int rows;
+};
+
+// NCH > 0: HW == NCH * RL and the image's chunks stay in registers; NCH == 0: any HW, second pass re-reads
+template <typename T, int NCH>
 __global__ __launch_bounds__(256) void k_se_fused_fwd(
-    const T* __restrict__ x, const float* __restrict__ bn_scale, const float* __restrict__ bn_shift,
-    const T* __restrict__ skip, T* __restrict__ y, int B, int HW, int C, int Hd, int imgs,
-    const float* __restrict__ w1, const float* __restrict__ b1, const float* __restrict__ w2,
+    const T* __restrict__ x, BnFromSlab bn, const T* __restrict__ skip, T* __restrict__ y, int B, int HW, int C,
+    int Hd, int imgs, const float* __restrict__ w1, const float* __restrict__ b1, const float* __restrict__ w2,
     const float* __restrict__ b2, float ss, float bs, float* __restrict__ pooled_sum,
-    float* __restrict__ gate_out, float* __restrict__ hidden_out, float* stats, BnFinArgs fin) {
+    float* __restrict__ gate_out, float* __restrict__ hidden_out, SefOut so) {
     __shared__ float p[SEF_MAX_C];
     __shared__ float part[2 * 2048];
     __shared__ float hd[SEF_MAX_H];
+    __shared__ float s_w1[SEF_W_LDS], s_w2[SEF_W_LDS];
+    __shared__ float s_sc[SEF_MAX_C], s_sh[SEF_MAX_C];
     const int CG = C >> 3, RL = 256 / CG;
     const int tg = threadIdx.x % CG, rl = threadIdx.x / CG;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const float inv_hw = 1.0f / (float)HW;
-    float sc[8], sh[8];
+    const bool has_bn = bn.slab != nullptr || bn.scale != nullptr;
+    const bool w_lds = C * Hd <= SEF_W_LDS;
+    constexpr int NR = NCH > 0 ? NCH : 1;
+    float xv[NR][8], kv[NR][8];
+    // ---- everything this workgroup will need, requested up front
+    long b = (long)blockIdx.x * imgs;
+    if constexpr (NCH > 0) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { sc[j] = bn_scale ? bn_scale[tg * 8 + j] : 1.f; sh[j] = bn_scale ? bn_shift[tg * 8 + j] : 0.f; }
+        for (int i = 0; i < NCH; ++i) {
+            V8<T>::ld(x + (b * HW + rl + i * RL) * C + tg * 8, xv[i]);
+            V8<T>::ld(skip + (b * HW + rl + i * RL) * C + tg * 8, kv[i]);
+        }
+    }
+    if (w_lds)
+        for (int i = threadIdx.x; i < C * Hd; i += 256) { s_w1[i] = w1[i]; s_w2[i] = w2[i]; }
+    if (has_bn)
+        for (int c = threadIdx.x; c < C; c += 256) {
+            float sc, sh;
+            bn_coef(bn, C, c, blockIdx.x == 0, sc, sh);
+            s_sc[c] = sc; s_sh[c] = sh;
+        }
     float st[2][8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) { st[0][j] = 0.f; st[1][j] = 0.f; }
-    for (int im = 0; im < imgs; ++im) {
-        const long b = (long)blockIdx.x * imgs + im;
+    for (int im = 0; im < imgs; ++im, ++b) {
         if (b >= B) break;
         const T* xb = x + b * HW * C;
         const T* kb = skip + b * HW * C;
         T* yb = y + b * HW * C;
+        if (NCH > 0 && im > 0) {
+#pragma unroll
+            for (int i = 0; i < NR; ++i) {
+                V8<T>::ld(xb + (long)(rl + i * RL) * C + tg * 8, xv[i]);
+                V8<T>::ld(kb + (long)(rl + i * RL) * C + tg * 8, kv[i]);
+            }
+        }
         // ---- pool (raw sums; the BatchNorm is affine per channel)
         float a[1][8] = {{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}};
-        for (int r = rl; r < HW; r += RL) {
-            float v[8];
-            V8<T>::ld(xb + (long)r * C + tg * 8, v);
+        if constexpr (NCH > 0) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) a[0][j] += v[j];
+            for (int i = 0; i < NCH; ++i)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) a[0][j] += xv[i][j];
+        } else {
+            for (int r = rl; r < HW; r += RL) {
+                float v[8];
+                V8<T>::ld(xb + (long)r * C + tg * 8, v);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) a[0][j] += v[j];
+            }
         }
-        __syncthreads();                       // previous image's readers of p / part / hd are done
+        __syncthreads();                       // previous image's readers of p / part / hd are done; tables are written
         sef_scatter<1>(part, a, rl, tg, C);
         __syncthreads();
         for (int c = threadIdx.x; c < C; c += 256) {
             float v = sef_gather(part, 0, c, C, RL);
-            if (bn_scale) v = bn_scale[c] * v + (float)HW * bn_shift[c];
+            if (has_bn) v = s_sc[c] * v + (float)HW * s_sh[c];
             pooled_sum[b * C + c] = v;
             p[c] = v * inv_hw;
         }
         __syncthreads();
         // ---- hidden = relu(p W1 + b1); gate = sigmoid(hidden W2 + b2)
+        const float* W1 = w_lds ? s_w1 : w1;
+        const float* W2 = w_lds ? s_w2 : w2;
         for (int h = wave; h < Hd; h += 4) {
             float acc = 0.f;
-            for (int c = lane; c < C; c += 64) acc += p[c] * w1[(long)c * Hd + h];
+            for (int c = lane; c < C; c += 64) acc += p[c] * W1[(long)c * Hd + h];
             acc = wave_sum(acc);
             if (lane == 0) {
                 const float v = fmaxf(acc + b1[h], 0.f);
@@ -95,45 +136,61 @@ __global__ __launch_bounds__(256) void k_se_fused_fwd(
         __syncthreads();
         for (int c = threadIdx.x; c < C; c += 256) {
             float acc = b2[c];
-            for (int h = 0; h < Hd; ++h) acc += hd[h] * w2[(long)h * C + c];
+            for (int h = 0; h < Hd; ++h) acc += hd[h] * W2[(long)h * C + c];
             const float g = sigmoidf_(acc);
             gate_out[b * C + c] = g;
             p[c] = g;
         }
         __syncthreads();
         // ---- y = ss*skip + bs * BN(x) * gate (+ statistics of y)
-        float g8[8];
+        float g8[8], sc[8], sh[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) g8[j] = p[tg * 8 + j] * bs;
-        for (int r = rl; r < HW; r += RL) {
-            float v[8], k[8];
-            V8<T>::ld(xb + (long)r * C + tg * 8, v);
-            V8<T>::ld(kb + (long)r * C + tg * 8, k);
+        for (int j = 0; j < 8; ++j) {
+            g8[j] = p[tg * 8 + j] * bs;
+            sc[j] = has_bn ? s_sc[tg * 8 + j] : 1.f;
+            sh[j] = has_bn ? s_sh[tg * 8 + j] : 0.f;
+        }
+        if constexpr (NCH > 0) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                v[j] = ss * k[j] + (v[j] * sc[j] + sh[j]) * g8[j];
-                st[0][j] += v[j]; st[1][j] += v[j] * v[j];
+            for (int i = 0; i < NCH; ++i) {
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    v[j] = ss * kv[i][j] + (xv[i][j] * sc[j] + sh[j]) * g8[j];
+                    st[0][j] += v[j]; st[1][j] += v[j] * v[j];
+                }
+                V8<T>::st(yb + (long)(rl + i * RL) * C + tg * 8, v);
             }
-            V8<T>::st(yb + (long)r * C + tg * 8, v);
+        } else {
+            for (int r = rl; r < HW; r += RL) {
+                float v[8], k[8];
+                V8<T>::ld(xb + (long)r * C + tg * 8, v);
+                V8<T>::ld(kb + (long)r * C + tg * 8, k);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    v[j] = ss * k[j] + (v[j] * sc[j] + sh[j]) * g8[j];
+                    st[0][j] += v[j]; st[1][j] += v[j] * v[j];
+                }
+                V8<T>::st(yb + (long)r * C + tg * 8, v);
+            }
         }
     }
-    if (!stats) return;
+    if (!so.stats) return;
     __syncthreads();
     sef_scatter<2>(part, st, rl, tg, C);
     __syncthreads();
+    const int row = blockIdx.x % so.rows;          // <= 64 adders per address (see conv_gemm.hip)
     for (int c = threadIdx.x; c < C; c += 256) {
-        bn_store_partial(stats + ((long)blockIdx.x * 2) * C + c, sef_gather(part, 0, c, C, RL));
-        bn_store_partial(stats + ((long)blockIdx.x * 2 + 1) * C + c, sef_gather(part, 1, c, C, RL));
+        atomicAdd(so.stats + ((long)row * 2) * C + c, sef_gather(part, 0, c, C, RL));
+        atomicAdd(so.stats + ((long)row * 2 + 1) * C + c, sef_gather(part, 1, c, C, RL));
     }
-    if (fin.counter == nullptr) return;
-    if (!bn_last_arriver(fin.counter, (int)gridDim.x)) return;
-    bn_fin_fwd(fin, stats, (int)gridDim.x, C, 0, (C + 63) / 64);
 }
 
-// images per workgroup such that the statistics slab has at most MAX rows
-static inline int sef_imgs(int B, int max_rows) { return (B + max_rows - 1) / max_rows; }
+// images per workgroup: at most 128 workgroups (more would not fill the chip any better at these sizes)
+static inline int sef_imgs(int B) { return (B + 127) / 128; }
+static inline int sef_wgs(int B) { return cdiv(B, sef_imgs(B)); }
 
-extern "C" int nvae_se_fused_rows(int B) { return B <= 0 ? 0 : cdiv(B, sef_imgs(B, 128)); }
+extern "C" int nvae_se_fused_rows(int B) { return B <= 0 ? 0 : cdiv(sef_wgs(B), 64); }
 
 static int sef_check(const char* who, int B, int HW, int C, int Hd) {
     NVAE_REQUIRE(B > 0 && HW > 0 && C >= 8 && C <= SEF_MAX_C && (C & (C - 1)) == 0 && Hd > 0 && Hd <= SEF_MAX_H,
@@ -141,28 +198,39 @@ static int sef_check(const char* who, int B, int HW, int C, int Hd) {
     return NVAE_OK;
 }
 
-extern "C" int nvae_se_fused_fwd(int dtype, const void* x, const float* bn_scale, const float* bn_shift,
-                                 const void* skip, void* y, int B, int HW, int C, int Hd, const float* w1,
-                                 const float* b1, const float* w2, const float* b2, float skip_scale,
-                                 float branch_scale, float* pooled_sum, float* gate, float* hidden, float* stats,
-                                 const NvaeBnFin* fin, void* stream) {
+static int sef_bn(const char* who, const NvaeBnIn* in, long rows, BnFromSlab& bn) {
+    bn = BnFromSlab{};
+    if (!in) return NVAE_OK;
+    NVAE_REQUIRE(in->scale && in->shift, "%s: NvaeBnIn needs scale / shift", who);
+    bn.scale = in->scale; bn.shift = in->shift; bn.mean = in->mean; bn.invstd = in->invstd;
+    if (in->slab) {
+        NVAE_REQUIRE(in->rows > 0 && in->gamma && in->beta && in->rm && in->rv && in->mean && in->invstd,
+                     "%s: NvaeBnIn with a slab needs rows, gamma, beta, rm, rv, mean, invstd", who);
+        bn.slab = in->slab; bn.rows = in->rows; bn.inv_n = 1.0f / (float)rows; bn.eps = in->eps; bn.momentum = in->momentum;
+        bn.gamma = in->gamma; bn.beta = in->beta; bn.rm = in->rm; bn.rv = in->rv;
+    }
+    return NVAE_OK;
+}
+
+extern "C" int nvae_se_fused_fwd(int dtype, const void* x, const NvaeBnIn* bn_in, const void* skip, void* y, int B,
+                                 int HW, int C, int Hd, const float* w1, const float* b1, const float* w2,
+                                 const float* b2, float skip_scale, float branch_scale, float* pooled_sum,
+                                 float* gate, float* hidden, float* stats, void* stream) {
     if (int e = sef_check("se_fused_fwd", B, HW, C, Hd)) return e;
     NVAE_REQUIRE(aligned16(x) && aligned16(skip) && aligned16(y) && w1 && b1 && w2 && b2 && pooled_sum && gate && hidden,
                  "se_fused_fwd: alignment / NULL argument");
-    NVAE_REQUIRE((bn_scale == nullptr) == (bn_shift == nullptr), "se_fused_fwd: scale and shift go together");
-    NVAE_REQUIRE(!fin || stats, "se_fused_fwd: an in-kernel finalize needs the statistics slab");
-    BnFinArgs f{};
-    if (fin) {
-        NVAE_REQUIRE(fin->counter && fin->gamma && fin->beta && fin->rm && fin->rv && fin->scale && fin->shift &&
-                     fin->mean && fin->invstd, "se_fused_fwd: NULL field in NvaeBnFin");
-        f.counter = fin->counter; f.inv_n = 1.0f / (float)((long)B * HW); f.gamma = fin->gamma; f.beta = fin->beta;
-        f.rm = fin->rm; f.rv = fin->rv; f.momentum = fin->momentum; f.eps = fin->eps; f.scale = fin->scale;
-        f.shift = fin->shift; f.mean = fin->mean; f.invstd = fin->invstd;
-    }
-    const int imgs = sef_imgs(B, 128);
-    DISPATCH_T(dtype, hipLaunchKernelGGL((k_se_fused_fwd<T>), cdiv(B, imgs), 256, 0, (hipStream_t)stream, (const T*)x,
-                                         bn_scale, bn_shift, (const T*)skip, (T*)y, B, HW, C, Hd, imgs, w1, b1, w2, b2,
-                                         skip_scale, branch_scale, pooled_sum, gate, hidden, stats, f);)
+    BnFromSlab bn;
+    if (int e = sef_bn("se_fused_fwd", bn_in, (long)B * HW, bn)) return e;
+    const int imgs = sef_imgs(B), wgs = sef_wgs(B);
+    SefOut so{stats, cdiv(wgs, 64)};
+    const int RL = 256 / (C / 8);
+    const int nch = (HW % RL == 0) ? HW / RL : 0;
+#define SEF_LAUNCH(N_)                                                                                              \
+    DISPATCH_T(dtype, hipLaunchKernelGGL((k_se_fused_fwd<T, N_>), wgs, 256, 0, (hipStream_t)stream, (const T*)x, bn, \
+                                         (const T*)skip, (T*)y, B, HW, C, Hd, imgs, w1, b1, w2, b2, skip_scale,      \
+                                         branch_scale, pooled_sum, gate, hidden, so);)
+    if (nch == 1) SEF_LAUNCH(1) else if (nch == 2) SEF_LAUNCH(2) else if (nch == 4) SEF_LAUNCH(4) else SEF_LAUNCH(0)
+#undef SEF_LAUNCH
     NVAE_LAUNCH_CHECK("se_fused_fwd");
     return NVAE_OK;
 }
@@ -172,44 +240,76 @@ extern "C" int nvae_se_fused_fwd(int dtype, const void* x, const float* bn_scale
 //   dxs = bs*dy*gate + dpool;   dskip (+)= ss*dy
 // dpre2 | dpre1 go to `scratch` ([B*C] | [B*Hd]) for the FC parameter gradients (nvae_se_wgrad_batched).
 // partials != NULL: xs = act(BN(x)) had no other consumer, so dxs is final and the BatchNorm-backward sums
-// (sum dpre, sum dpre*x with dpre = dxs * act'(scale*x + shift)) are reduced here: partials[rows][2][C].
-template <typename T>
+// (sum dpre, sum dpre*x with dpre = dxs * act'(scale*x + shift)) are reduced here into the ZEROED partials[rows][2][C].
+template <typename T, int NCH>
 __global__ __launch_bounds__(256) void k_se_fused_bwd(
     const T* __restrict__ x, const float* __restrict__ bn_scale, const float* __restrict__ bn_shift, int act,
     const T* __restrict__ dy, const float* __restrict__ gate, const float* __restrict__ hidden, T* dx, T* dskip,
     int B, int HW, int C, int Hd, int imgs, const float* __restrict__ w1, const float* __restrict__ w2, float ss,
-    float bs, int acc_dx, int acc_dskip, float* __restrict__ scratch, float* partials, BnFinArgs fin) {
+    float bs, int acc_dx, int acc_dskip, float* __restrict__ scratch, SefOut so) {
     __shared__ float d2[SEF_MAX_C];
     __shared__ float part[2 * 2048];
     __shared__ float d1[SEF_MAX_H];
+    __shared__ float s_w1[SEF_W_LDS], s_w2[SEF_W_LDS];
     const int CG = C >> 3, RL = 256 / CG;
     const int tg = threadIdx.x % CG, rl = threadIdx.x / CG;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const float inv_hw = 1.0f / (float)HW;
+    const bool w_lds = C * Hd <= SEF_W_LDS;
     float* dpre2_out = scratch;
     float* dpre1_out = scratch + (long)B * C;
+    float* partials = so.stats;
+    constexpr int NR = NCH > 0 ? NCH : 1;
+    float xv[NR][8], gv[NR][8];
+    long b = (long)blockIdx.x * imgs;
+    if constexpr (NCH > 0) {
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            V8<T>::ld(x + (b * HW + rl + i * RL) * C + tg * 8, xv[i]);
+            V8<T>::ld(dy + (b * HW + rl + i * RL) * C + tg * 8, gv[i]);
+        }
+    }
+    if (w_lds)
+        for (int i = threadIdx.x; i < C * Hd; i += 256) { s_w1[i] = w1[i]; s_w2[i] = w2[i]; }
     float sc[8], sh[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) { sc[j] = bn_scale ? bn_scale[tg * 8 + j] : 1.f; sh[j] = bn_scale ? bn_shift[tg * 8 + j] : 0.f; }
     float st[2][8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) { st[0][j] = 0.f; st[1][j] = 0.f; }
-    for (int im = 0; im < imgs; ++im) {
-        const long b = (long)blockIdx.x * imgs + im;
+    for (int im = 0; im < imgs; ++im, ++b) {
         if (b >= B) break;
         const T* xb = x + b * HW * C;
         const T* gb = dy + b * HW * C;
-        // ---- r = sum xs*dy  (xs = act(scale*x + shift); for act = none: scale * sum x*dy + shift * sum dy)
-        float a[1][8] = {{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}};
-        for (int r = rl; r < HW; r += RL) {
-            float v[8], g[8];
-            V8<T>::ld(xb + (long)r * C + tg * 8, v);
-            V8<T>::ld(gb + (long)r * C + tg * 8, g);
+        if (NCH > 0 && im > 0) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                float xs = v[j] * sc[j] + sh[j];
-                if (act == ACT_SWISH) xs = swishf_(xs);
-                a[0][j] += xs * g[j];
+            for (int i = 0; i < NR; ++i) {
+                V8<T>::ld(xb + (long)(rl + i * RL) * C + tg * 8, xv[i]);
+                V8<T>::ld(gb + (long)(rl + i * RL) * C + tg * 8, gv[i]);
+            }
+        }
+        // ---- r = sum xs*dy  (xs = act(scale*x + shift))
+        float a[1][8] = {{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}};
+        if constexpr (NCH > 0) {
+#pragma unroll
+            for (int i = 0; i < NCH; ++i)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    float xs = xv[i][j] * sc[j] + sh[j];
+                    if (act == ACT_SWISH) xs = swishf_(xs);
+                    a[0][j] += xs * gv[i][j];
+                }
+        } else {
+            for (int r = rl; r < HW; r += RL) {
+                float v[8], g[8];
+                V8<T>::ld(xb + (long)r * C + tg * 8, v);
+                V8<T>::ld(gb + (long)r * C + tg * 8, g);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    float xs = v[j] * sc[j] + sh[j];
+                    if (act == ACT_SWISH) xs = swishf_(xs);
+                    a[0][j] += xs * g[j];
+                }
             }
         }
         __syncthreads();
@@ -223,9 +323,11 @@ __global__ __launch_bounds__(256) void k_se_fused_bwd(
             dpre2_out[b * C + c] = d;
         }
         __syncthreads();
+        const float* W1 = w_lds ? s_w1 : w1;
+        const float* W2 = w_lds ? s_w2 : w2;
         for (int h = wave; h < Hd; h += 4) {
             float acc = 0.f;
-            for (int c = lane; c < C; c += 64) acc += w2[(long)h * C + c] * d2[c];
+            for (int c = lane; c < C; c += 64) acc += W2[(long)h * C + c] * d2[c];
             acc = wave_sum(acc);
             if (lane == 0) {
                 const float d = hidden[b * Hd + h] > 0.f ? acc : 0.f;
@@ -236,7 +338,7 @@ __global__ __launch_bounds__(256) void k_se_fused_bwd(
         __syncthreads();
         for (int c = threadIdx.x; c < C; c += 256) {
             float acc = 0.f;
-            for (int h = 0; h < Hd; ++h) acc += w1[(long)c * Hd + h] * d1[h];
+            for (int h = 0; h < Hd; ++h) acc += W1[(long)c * Hd + h] * d1[h];
             d2[c] = acc * inv_hw;              // dpool
         }
         __syncthreads();
@@ -245,13 +347,10 @@ __global__ __launch_bounds__(256) void k_se_fused_bwd(
         for (int j = 0; j < 8; ++j) { g8[j] = gate[b * C + tg * 8 + j] * bs; dp[j] = d2[tg * 8 + j]; }
         T* dxb = dx + b * HW * C;
         T* dkb = dskip ? dskip + b * HW * C : nullptr;
-        for (int r = rl; r < HW; r += RL) {
-            const long off = (long)r * C + tg * 8;
-            float g[8], o[8], k[8], v[8];
-            V8<T>::ld(gb + off, g);
+        auto apply = [&](long off, const float (&g)[8], const float (&v)[8]) {
+            float o[8], k[8];
             if (acc_dx) V8<T>::ld(dxb + off, o);
             if (dkb && acc_dskip) V8<T>::ld(dkb + off, k);
-            if (partials) V8<T>::ld(xb + off, v);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const float d = g[j] * g8[j] + dp[j];
@@ -265,19 +364,29 @@ __global__ __launch_bounds__(256) void k_se_fused_bwd(
             }
             V8<T>::st(dxb + off, o);
             if (dkb) V8<T>::st(dkb + off, k);
+        };
+        if constexpr (NCH > 0) {
+#pragma unroll
+            for (int i = 0; i < NCH; ++i) apply((long)(rl + i * RL) * C + tg * 8, gv[i], xv[i]);
+        } else {
+            for (int r = rl; r < HW; r += RL) {
+                const long off = (long)r * C + tg * 8;
+                float g[8], v[8];
+                V8<T>::ld(gb + off, g);
+                V8<T>::ld(xb + off, v);
+                apply(off, g, v);
+            }
         }
     }
     if (!partials) return;
     __syncthreads();
     sef_scatter<2>(part, st, rl, tg, C);
     __syncthreads();
+    const int row = blockIdx.x % so.rows;
     for (int c = threadIdx.x; c < C; c += 256) {
-        bn_store_partial(partials + ((long)blockIdx.x * 2) * C + c, sef_gather(part, 0, c, C, RL));
-        bn_store_partial(partials + ((long)blockIdx.x * 2 + 1) * C + c, sef_gather(part, 1, c, C, RL));
+        atomicAdd(partials + ((long)row * 2) * C + c, sef_gather(part, 0, c, C, RL));
+        atomicAdd(partials + ((long)row * 2 + 1) * C + c, sef_gather(part, 1, c, C, RL));
     }
-    if (fin.counter == nullptr) return;
-    if (!bn_last_arriver(fin.counter, (int)gridDim.x)) return;
-    bn_fin_bwd(fin, partials, (int)gridDim.x, C, 0, (C + 63) / 64);
 }
 
 extern "C" int nvae_se_fused_bwd(int dtype, const void* x, const float* bn_scale, const float* bn_shift, int act,
@@ -292,12 +401,16 @@ extern "C" int nvae_se_fused_bwd(int dtype, const void* x, const float* bn_scale
     NVAE_REQUIRE(act == ACT_NONE || (act == ACT_SWISH && bn_scale), "se_fused_bwd: act %d unsupported", act);
     NVAE_REQUIRE(dskip || !acc_dskip, "se_fused_bwd: acc_dskip without dskip");
     NVAE_REQUIRE(!partials || (bn_scale && !acc_dx), "se_fused_bwd: BatchNorm sums need the coefficients and a final dx");
-    BnFinArgs f{};
-    const int imgs = sef_imgs(B, 128);
-    DISPATCH_T(dtype, hipLaunchKernelGGL((k_se_fused_bwd<T>), cdiv(B, imgs), 256, 0, (hipStream_t)stream, (const T*)x,
-                                         bn_scale, bn_shift, act, (const T*)dy, gate, hidden, (T*)dx, (T*)dskip, B, HW, C,
-                                         Hd, imgs, w1, w2, skip_scale, branch_scale, acc_dx, dskip ? acc_dskip : 0,
-                                         scratch, partials, f);)
+    const int imgs = sef_imgs(B), wgs = sef_wgs(B);
+    SefOut so{partials, cdiv(wgs, 64)};
+    const int RL = 256 / (C / 8);
+    const int nch = (HW % RL == 0) ? HW / RL : 0;
+#define SEF_LAUNCH(N_)                                                                                                \
+    DISPATCH_T(dtype, hipLaunchKernelGGL((k_se_fused_bwd<T, N_>), wgs, 256, 0, (hipStream_t)stream, (const T*)x, bn_scale, \
+                                         bn_shift, act, (const T*)dy, gate, hidden, (T*)dx, (T*)dskip, B, HW, C, Hd, imgs,  \
+                                         w1, w2, skip_scale, branch_scale, acc_dx, dskip ? acc_dskip : 0, scratch, so);)
+    if (nch == 1) SEF_LAUNCH(1) else if (nch == 2) SEF_LAUNCH(2) else if (nch == 4) SEF_LAUNCH(4) else SEF_LAUNCH(0)
+#undef SEF_LAUNCH
     NVAE_LAUNCH_CHECK("se_fused_bwd");
     return NVAE_OK;
 }

@@ -61,8 +61,14 @@ FUSED_FIN = os.environ.get("NVAE_BN_FUSED_FIN", "1") != "0"
 APPLY_FIN = os.environ.get("NVAE_BN_APPLY_FIN", "1") != "0"   # slab -> coefficients inside the apply kernels
 SE_STATS = os.environ.get("NVAE_SE_STATS", "1") != "0"         # BN statistics out of the SE + residual kernel
 SE_FUSED = os.environ.get("NVAE_SE_FUSED", "1") != "0"         # SE + residual (+ the BatchNorm in front) as one launch
-CONV_PRE = os.environ.get("NVAE_CONV_PRE", "1") != "0"         # BatchNorm(+Swish) applied in the consuming conv's operand prologue
-STATS_FIN = os.environ.get("NVAE_STATS_FIN", "1") != "0"       # producers finalize the next BatchNorm in-kernel (last arriver)
+# BatchNorm(+Swish) applied in the consuming conv's operand prologue (nvae_conv_gemm_ex): "0" never, "1" where it
+# measured faster than the separate apply pass (1x1 convs behind a BatchNorm WITHOUT activation: an im2col operand
+# is transformed once per tap and N-tile, which for Swish costs more VALU time than the pass it removes;
+# tools/bench_pre.py), "all" wherever the geometry allows (tests)
+CONV_PRE = os.environ.get("NVAE_CONV_PRE", "1")
+# producers finalize the next BatchNorm in-kernel ("last arriver"): measured +5..12 us per conv launch against the
+# 4.8 us of a finalize launch or the ~0 of a consumer that reads the accumulated slab itself, so off by default
+STATS_FIN = os.environ.get("NVAE_STATS_FIN", "0") != "0"
 FUSE_BN_BWD = os.environ.get("NVAE_BN_BWD_FUSE", "1") != "0"   # BN backward sums in the dgrad epilogue
 
 
@@ -302,7 +308,8 @@ def conv2d(ctx: Ctx, x: Var, conv, *, stride: int = 1, up: int = 1, pad: Optiona
     # operand prologue: x = act(BN(raw)) is applied inside the conv kernel (and, for the weight gradient, written
     # out once by it) when the gather is not upsampled and covers every source pixel as some output's centre tap
     lib = L.load()
-    use_pre = (CONV_PRE and fwd_mfma and x.pre is not None and x.pre.mat is None and up == 1 and cin == Cx and c_off == 0
+    pre_pays = CONV_PRE == "all" or (CONV_PRE == "1" and k == 1 and x.pre is not None and x.pre.act == L.ACT_NONE)
+    use_pre = (pre_pays and fwd_mfma and x.pre is not None and x.pre.mat is None and up == 1 and cin == Cx and c_off == 0
                and 0 < Cx <= lib.nvae_conv_gemm_pre_max_cin(ctx.dt, C.byref(g))
                and (not ctx.record or (stride == 1 and (Ho, Wo) == (H, W) and 0 <= pad[0] < k and 0 <= pad[1] < k)))
     x_act: Optional[torch.Tensor] = None      # the activated input as the backward pass will read it
@@ -311,18 +318,17 @@ def conv2d(ctx: Ctx, x: Var, conv, *, stride: int = 1, up: int = 1, pad: Optiona
         slab, fin = None, None
         if want_stats and ctx.training and not accumulate and out_coff == 0 and Cy == cout:
             # the conv's epilogue emits the BatchNorm statistics of its output (consumed by bn_act)
-            S = lib.nvae_conv_gemm_mtiles(ctx.dt, C.byref(g))
-            slab = ctx.empty((S, 2, cout), torch.float32)
+            S = lib.nvae_conv_gemm_stats_rows(ctx.dt, C.byref(g))
+            slab = ctx.zeros_f32(S * 2 * cout).view(S, 2, cout)      # accumulated into with atomics
             out.stats = (slab, S)
             if want_fin(ctx, stats_bn):
                 coef = ctx.empty((4, cout), torch.float32)
                 fin = C.byref(bn_fin_struct(ctx, stats_bn, coef))
                 out.fin = (stats_bn, coef)
         if use_pre:
-            sc, sh = x.pre.coef()
             if ctx.record:
                 x_act = ctx.empty(x.shape)
-            pre = L.ConvPre(sc, sh, x.pre.act, ptr(x_act), Cx)
+            pre = L.ConvPre(x.pre.bn_in(), x.pre.act, ptr(x_act), Cx)
             call("nvae_conv_gemm_ex", ctx.dt, C.byref(g), ptr(x.raw), wT, conv.wf_ld, bias_ptr, res_ptr, out_ptr,
                  int(out_f32), ptr(slab), C.byref(pre), fin)
         elif fin is not None:
@@ -379,8 +385,8 @@ def conv2d(ctx: Ctx, x: Var, conv, *, stride: int = 1, up: int = 1, pad: Optiona
                     # x = act(BN(x0)) and this conv is its only consumer: reduce the BN backward sums in
                     # the epilogue of the data-gradient kernel (the BN closure then only applies)
                     wD = ptr(ps.wcopies) + conv.wd_off * ps.wcopies.element_size()
-                    mt = L.load().nvae_conv_gemm_mtiles(ctx.dt, C.byref(gd))
-                    src["partials"] = ctx.empty((mt, 2, Cx), torch.float32)
+                    mt = L.load().nvae_conv_gemm_stats_rows(ctx.dt, C.byref(gd))
+                    src["partials"] = ctx.zeros_f32(mt * 2 * Cx).view(mt, 2, Cx)
                     src["k0k1"] = ctx.empty((2, Cx), torch.float32)
                     src["mtiles"] = mt
                     f = L.BnBwdFuse(ptr(src["x"]), Cx, src["act"], src["frozen"], src["scale"], src["shift"],
@@ -414,7 +420,7 @@ def dwconv5(ctx: Ctx, x: Var, dw, want_stats: bool = False) -> Var:
     y = Var(ctx.empty(x.shape))
     rows = L.load().nvae_dwconv5_stats_rows(ctx.dt, B, H, W, Cc) if (want_stats and ctx.training) else 0
     if rows > 0:
-        slab = ctx.empty((rows, 2, Cc), torch.float32)
+        slab = ctx.zeros_f32(rows * 2 * Cc).view(rows, 2, Cc)       # accumulated into with atomics
         call("nvae_dwconv5_stats", ctx.dt, ptr(xt), ptr(ps.view(dw.w)), ptr(ps.view(dw.b)), ptr(y.t), B, H, W, Cc,
              ptr(slab))
         y.stats = (slab, rows)
@@ -480,6 +486,16 @@ class LazyBN:
                  self.shift, self.mean, self.invstd)
             self.ready = True
         return self.scale, self.shift
+
+    def bn_in(self) -> "L.BnIn":
+        """NvaeBnIn for a consumer kernel that applies this BatchNorm itself: the final table, or (first consumer
+        after a slab-only producer) the slab, which that kernel turns into the table."""
+        g, b, rm, rv = self._bn_args()
+        if self.ready:
+            return L.BnIn(None, 0, BN_MOMENTUM, BN_EPS, g, b, rm, rv, self.scale, self.shift, self.mean, self.invstd)
+        slab, Sx = self.x.stats
+        self.ready = True          # the consumer launched next publishes the table
+        return L.BnIn(ptr(slab), Sx, BN_MOMENTUM, BN_EPS, g, b, rm, rv, self.scale, self.shift, self.mean, self.invstd)
 
     def materialize(self) -> torch.Tensor:
         if self.mat is None:
@@ -601,24 +617,20 @@ def se_residual(ctx: Ctx, x: Var, se, skip: Var, skip_scale: float, branch_scale
     fused = _se_fused_ok(Cc, Hd)
     lazy_in = fused and x.pre is not None and x.pre.act == L.ACT_NONE and x.pre.mat is None
     if lazy_in:
-        pre_scale, pre_shift = x.pre.coef()
-        pre_act, xin_t = x.pre.act, x.raw
+        bn_in = C.byref(x.pre.bn_in())          # the kernel finishes the statistics itself if nobody has yet
+        pre_scale, pre_shift, pre_act, xin_t = x.pre.scale, x.pre.shift, x.pre.act, x.raw
     else:
-        pre_scale, pre_shift, pre_act, xin_t = None, None, L.ACT_NONE, x.t
+        bn_in, pre_scale, pre_shift, pre_act, xin_t = None, None, None, L.ACT_NONE, x.t
     y = Var(ctx.empty(x.shape))
     if fused:
         # pool + FC + gate + residual add (+ the BatchNorm in front, + the statistics of y) in ONE launch
-        slab, fin = None, None
+        slab = None
         if ctx.training and SE_STATS:
             S = L.load().nvae_se_fused_rows(B)
-            slab = ctx.empty((S, 2, Cc), torch.float32)
+            slab = ctx.zeros_f32(S * 2 * Cc).view(S, 2, Cc)
             y.stats = (slab, S)
-            if want_fin(ctx, stats_bn):
-                coef = ctx.empty((4, Cc), torch.float32)
-                fin = C.byref(bn_fin_struct(ctx, stats_bn, coef))
-                y.fin = (stats_bn, coef)
-        call("nvae_se_fused_fwd", ctx.dt, ptr(xin_t), pre_scale, pre_shift, ptr(skip.t), ptr(y.t), B, HW, Cc, Hd,
-             w1, b1, w2, b2, skip_scale, branch_scale, ptr(pooled), ptr(gate), ptr(hidden), ptr(slab), fin)
+        call("nvae_se_fused_fwd", ctx.dt, ptr(xin_t), bn_in, ptr(skip.t), ptr(y.t), B, HW, Cc, Hd,
+             w1, b1, w2, b2, skip_scale, branch_scale, ptr(pooled), ptr(gate), ptr(hidden), ptr(slab))
     else:
         if Cc <= 2048:
             call("nvae_se_pool_gate", ctx.dt, ptr(x.t), B, HW, Cc, Hd, w1, b1, w2, b2, ptr(pooled), ptr(gate), ptr(hidden))
@@ -652,7 +664,7 @@ def se_residual(ctx: Ctx, x: Var, se, skip: Var, skip_scale: float, branch_scale
                 if fuse:
                     # x = act(BN(xb)) with this SE as its only consumer: dx is final, reduce the BN backward sums here
                     S = L.load().nvae_se_fused_rows(B)
-                    src["partials"] = ctx.empty((S, 2, Cc), torch.float32)
+                    src["partials"] = ctx.zeros_f32(S * 2 * Cc).view(S, 2, Cc)
                     src["k0k1"] = ctx.empty((2, Cc), torch.float32)
                     src["mtiles"] = S
                     src["fused"] = True
