@@ -510,7 +510,7 @@ def test_dwconv5(lib, dev, dtype, B, H, W_, C_):
     rows = lib.nvae_dwconv5_stats_rows(ctx.dt, B, H, W_, C_)
     assert (rows > 0) == (dtype == torch.bfloat16)
     if rows:
-        slab = torch.full((rows, 2, C_), float("nan"), device=dev)
+        slab = torch.zeros((rows, 2, C_), device=dev)          # accumulated into with atomics: must be zero
         y2 = torch.empty_like(y.t)
         call("nvae_dwconv5_stats", ctx.dt, ptr(xv.t), ptr(ps.view(dw.w)), ptr(ps.view(dw.b)), ptr(y2), B, H, W_, C_,
              ptr(slab))
