@@ -142,12 +142,15 @@ int nvae_conv_gemm_bnbwd(int dtype, const NvaeConvGeom* g, const void* src, cons
  * pixel reduction is split over up to 256 workgroups per tile and combined through it instead of
  * through atomics.                                                                             */
 long nvae_conv_wgrad_scratch(int dtype, const NvaeConvGeom* g);
+/* per-layer scratch of an n-layer nvae_conv_wgrad_batched launch (the pixel split shrinks with n: a batch of
+ * same-shape layers fills the chip by itself, so from a few layers on no scratch is needed at all)  */
+long nvae_conv_wgrad_scratch_n(int dtype, const NvaeConvGeom* g, int n_layers);
 int nvae_conv_wgrad(int dtype, const NvaeConvGeom* g, const void* x, const void* dy, float* dw,
                     int dw_ld, float* db, float* scratch, long scratch_floats, void* stream);
 /* nvae_conv_wgrad for n <= 32 layers of the SAME geometry in one launch (the residual towers repeat one
  * conv shape 10-40 times per step; each of those weight gradients alone is a 10-15 us kernel).  x, dy, dw,
  * db: host arrays of n device pointers (db: NULL, or a pointer for every layer); scratch: n times
- * nvae_conv_wgrad_scratch(dtype, g) floats (scratch_floats_per_layer each).                          */
+ * nvae_conv_wgrad_scratch_n(dtype, g, n) floats (scratch_floats_per_layer each).                     */
 int nvae_conv_wgrad_batched(int dtype, const NvaeConvGeom* g, int n, const void* const* x,
                             const void* const* dy, float* const* dw, int dw_ld, float* const* db,
                             float* scratch, long scratch_floats_per_layer, void* stream);

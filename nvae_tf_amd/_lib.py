@@ -68,6 +68,7 @@ _SIGS = {
     "nvae_conv_gemm_pre_max_cin": None,
     "nvae_conv_gemm_bnbwd": [_i, _p, _p, _p, _i, _p, _p, _p, _p],
     "nvae_conv_wgrad_scratch": None,
+    "nvae_conv_wgrad_scratch_n": None,
     "nvae_conv_wgrad": [_i, _G, _p, _p, _p, _i, _p, _p, _l],
     "nvae_conv_wgrad_batched": [_i, _G, _i, _p, _p, _p, _i, _p, _p, _l],
     "nvae_conv_direct": [_i, _G, _p, _p, _l, _l, _l, _i, _p, _p, _p, _i],
@@ -163,6 +164,8 @@ def load():
     lib.nvae_conv_gemm_pre_max_cin.argtypes = [_i, _G]
     lib.nvae_conv_wgrad_scratch.restype = C.c_long
     lib.nvae_conv_wgrad_scratch.argtypes = [_i, _G]
+    lib.nvae_conv_wgrad_scratch_n.restype = C.c_long
+    lib.nvae_conv_wgrad_scratch_n.argtypes = [_i, _G, _i]
     for name, sig in _SIGS.items():
         if sig is None:
             continue

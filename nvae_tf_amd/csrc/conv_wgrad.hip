@@ -478,7 +478,7 @@ static void launch_wgrad_halo(const NvaeConvGeom* g, const void* x, const void* 
 // Split policy shared by the launcher and the scratch-size query.
 struct WgradPlan { int cfg, tiles, n_tiles, nsplit, mps; bool slab; };
 template <typename T>
-static WgradPlan plan_conv_wgrad(const NvaeConvGeom* g, long scratch_floats) {
+static WgradPlan plan_conv_wgrad(const NvaeConvGeom* g, long scratch_floats, int n_layers = 1) {
     constexpr int RS = 8 * Tr<T>::VE;
     const int M = g->B * g->Hout * g->Wout, K = g->KH * g->KW * g->Cin, N = g->Cout;
     const long flops = 2L * M * K * N;
@@ -490,8 +490,10 @@ static WgradPlan plan_conv_wgrad(const NvaeConvGeom* g, long scratch_floats) {
     p.n_tiles = cdiv(N, NTL);
     p.tiles = cdiv(K, KT) * p.n_tiles;
     // enough workgroups to fill the chip (one wave of 256 for the 8-wave config, ~2 per CU otherwise),
-    // at least 4 ring steps each
-    int nsplit = (p.cfg == 0 ? 256 : 512) / p.tiles;
+    // at least 4 ring steps each.  A batched launch already has n_layers times the tiles: the towers' 20-30
+    // same-shape layers fill the chip without any pixel split, i.e. without partial slabs (round 1 split every
+    // layer as if it were alone: 5 splits x 30 layers of the 256 -> 1536 convs wrote and re-read 237 MB of slabs)
+    int nsplit = (p.cfg == 0 ? 256 : 512) / (p.tiles * (n_layers < 1 ? 1 : n_layers));
     int max_split = M / (RS * 4);
     if (nsplit > max_split) nsplit = max_split;
     if (nsplit > 256) nsplit = 256;
@@ -521,7 +523,7 @@ static int launch_conv_wgrad(const NvaeConvGeom* g, int n, const void* const* x,
     FastDiv fd_hw = make_fastdiv((unsigned)(g->Hout * g->Wout)), fd_w = make_fastdiv((unsigned)g->Wout);
     const uint4* zeros = zero_page();
     // scratch_floats is the budget PER LAYER: all layers of a batch share one plan
-    const WgradPlan p = plan_conv_wgrad<T>(g, scratch ? scratch_floats : 0);
+    const WgradPlan p = plan_conv_wgrad<T>(g, scratch ? scratch_floats : 0, n);
     float* slab = p.slab ? scratch : nullptr;
     WgradBatch bt{};
     for (int i = 0; i < n; ++i) { bt.x[i] = x[i]; bt.dy[i] = dy[i]; bt.dw[i] = dw[i]; bt.db[i] = db ? db[i] : nullptr; }
@@ -539,12 +541,13 @@ static int launch_conv_wgrad(const NvaeConvGeom* g, int n, const void* const* x,
     return 0;
 }
 
-extern "C" long nvae_conv_wgrad_scratch(int dtype, const NvaeConvGeom* g) {
+extern "C" long nvae_conv_wgrad_scratch_n(int dtype, const NvaeConvGeom* g, int n_layers) {
     if (!g) return 0;
     const long K = (long)g->KH * g->KW * g->Cin, N = g->Cout;
-    WgradPlan p = dtype == NVAE_BF16 ? plan_conv_wgrad<bf16>(g, 1L << 60) : plan_conv_wgrad<float>(g, 1L << 60);
+    WgradPlan p = dtype == NVAE_BF16 ? plan_conv_wgrad<bf16>(g, 1L << 60, n_layers) : plan_conv_wgrad<float>(g, 1L << 60, n_layers);
     return p.slab ? (long)p.nsplit * (K + 1) * N : 0;
 }
+extern "C" long nvae_conv_wgrad_scratch(int dtype, const NvaeConvGeom* g) { return nvae_conv_wgrad_scratch_n(dtype, g, 1); }
 
 static int check_wgrad_args(const char* who, int dtype, const NvaeConvGeom* g, int dw_ld) {
     if (int e = check_geom_mfma(who, g)) return e;

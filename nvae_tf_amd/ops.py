@@ -174,21 +174,21 @@ class Ctx:
         lib = L.load()
         for key, items in groups.items():
             gw, dw_ld = items[0][1], key[1]
-            need = lib.nvae_conv_wgrad_scratch(self.dt, C.byref(gw))
             for i0 in range(0, len(items), 32):
                 chunk = items[i0:i0 + 32]
                 seen, run = set(), []
                 for it in chunk + [None]:            # a weight that appears twice must not share a launch
                     if it is None or it[4] in seen:
-                        self._launch_wgrad_batch(gw, dw_ld, need, run)
+                        self._launch_wgrad_batch(gw, dw_ld, run)
                         seen, run = set(), []
                     if it is not None:
                         seen.add(it[4]); run.append(it)
 
-    def _launch_wgrad_batch(self, gw, dw_ld, need, run):
+    def _launch_wgrad_batch(self, gw, dw_ld, run):
         n = len(run)
         if n == 0:
             return
+        need = L.load().nvae_conv_wgrad_scratch_n(self.dt, C.byref(gw), n)     # the pixel split shrinks with n
         scratch = self.empty((n * need,), torch.float32) if need else None
         if scratch is not None:
             self.keep.append(scratch)
