@@ -981,62 +981,6 @@ template <typename T>
 __global__ __launch_bounds__(RED_THREADS) void k_bn_apply_fin(
     const T* __restrict__ x, T* __restrict__ y, long rows, int C, int rows_per_block,
     const float* __restrict__ partials, int S, BnFinArgs a, int act) {
-    if (S <= 8) {
-        // Accumulated slab of a few rows (the producers add into it with atomics): every thread derives the
-        // coefficients of its own 8 channels straight from it - no LDS, no barrier - and its tensor loads are
-        // issued before the slab's have returned: ONE memory round trip instead of two.
-        const int TGS = C >= 64 ? 8 : (C > 16 ? (C > 32 ? 8 : 4) : (C > 8 ? 2 : 1));
-        const int RL = RED_THREADS / TGS;
-        const int tg = threadIdx.x % TGS, rl = threadIdx.x / TGS;
-        const int c0 = blockIdx.x * 64 + tg * 8;
-        if (c0 >= C) return;
-        const long r0 = (long)blockIdx.y * rows_per_block;
-        long r1 = r0 + rows_per_block;
-        if (r1 > rows) r1 = rows;
-        float v0[8];
-        const bool first = r0 + rl < r1;
-        if (first) V8<T>::ld(x + (r0 + rl) * (long)C + c0, v0);
-        float s1[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, s2[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        for (int r = 0; r < S; ++r) {
-            float t1[8], t2[8];
-            ld8f(partials + ((long)r * 2) * C + c0, t1);
-            ld8f(partials + ((long)r * 2 + 1) * C + c0, t2);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) { s1[j] += t1[j]; s2[j] += t2[j]; }
-        }
-        float sc[8], sh[8];
-        const bool publish = blockIdx.y == 0 && rl == 0;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const float m = s1[j] * a.inv_n;
-            const float var = fmaxf(s2[j] * a.inv_n - m * m, 0.f);
-            const float is = rsqrtf(var + a.eps);
-            sc[j] = a.gamma[c0 + j] * is;
-            sh[j] = a.beta[c0 + j] - m * sc[j];
-            if (publish) {
-                const int c = c0 + j;
-                a.scale[c] = sc[j]; a.shift[c] = sh[j]; a.mean[c] = m; a.invstd[c] = is;
-                a.rm[c] = a.rm[c] * a.momentum + m * (1.f - a.momentum);
-                a.rv[c] = a.rv[c] * a.momentum + var * (1.f - a.momentum);
-            }
-        }
-        for (long r = r0 + rl; r < r1; r += RL) {
-            float v[8];
-            if (r == r0 + rl) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = v0[j];
-            } else {
-                V8<T>::ld(x + r * (long)C + c0, v);
-            }
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float p = v[j] * sc[j] + sh[j];
-                v[j] = (act == ACT_SWISH) ? swishf_(p) : p;
-            }
-            V8<T>::st(y + r * (long)C + c0, v);
-        }
-        return;
-    }
     __shared__ float s_sc[64], s_sh[64];
     {
         int c; float s1, s2;
@@ -1106,60 +1050,6 @@ template <typename T>
 __global__ __launch_bounds__(RED_THREADS) void k_bn_bwd_apply_fin(
     const T* __restrict__ x, const T* __restrict__ dy, T* dx, long rows, int C, int rows_per_block,
     const float* __restrict__ partials, int S, BnFinArgs a, const float* __restrict__ shift, int act, int acc) {
-    if (S <= 8) {
-        // as in k_bn_apply_fin: coefficients per thread straight from the accumulated slab, one round trip
-        const int TGS = C >= 64 ? 8 : (C > 16 ? (C > 32 ? 8 : 4) : (C > 8 ? 2 : 1));
-        const int RL = RED_THREADS / TGS;
-        const int tg = threadIdx.x % TGS, rl = threadIdx.x / TGS;
-        const int c0 = blockIdx.x * 64 + tg * 8;
-        if (c0 >= C) return;
-        const long r0 = (long)blockIdx.y * rows_per_block;
-        long r1 = r0 + rows_per_block;
-        if (r1 > rows) r1 = rows;
-        float v0[8], g0[8];
-        const bool first = r0 + rl < r1;
-        if (first) { V8<T>::ld(x + (r0 + rl) * (long)C + c0, v0); V8<T>::ld(dy + (r0 + rl) * (long)C + c0, g0); }
-        float s1[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, s2[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        for (int r = 0; r < S; ++r) {
-            float t1[8], t2[8];
-            ld8f(partials + ((long)r * 2) * C + c0, t1);
-            ld8f(partials + ((long)r * 2 + 1) * C + c0, t2);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) { s1[j] += t1[j]; s2[j] += t2[j]; }
-        }
-        float sc[8], sh[8], k0[8], k1[8];
-        const bool publish = blockIdx.y == 0 && rl == 0;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int c = c0 + j;
-            const float m = a.mean[c], is = a.invstd[c];
-            sc[j] = a.scale[c]; sh[j] = shift[c];
-            const float dg = is * (s2[j] - m * s1[j]);
-            k1[j] = a.frozen ? 0.f : -sc[j] * dg * is * a.inv_n;
-            k0[j] = a.frozen ? 0.f : -sc[j] * s1[j] * a.inv_n - k1[j] * m;
-            if (publish) { a.dgamma[c] += dg; a.dbeta[c] += s1[j]; }
-        }
-        for (long r = r0 + rl; r < r1; r += RL) {
-            const long off = r * (long)C + c0;
-            float v[8], g[8], o[8];
-            if (r == r0 + rl) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) { v[j] = v0[j]; g[j] = g0[j]; }
-            } else {
-                V8<T>::ld(x + off, v);
-                V8<T>::ld(dy + off, g);
-            }
-            if (acc) V8<T>::ld(dx + off, o);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                float dpre = g[j];
-                if (act == ACT_SWISH) dpre *= dswishf_(v[j] * sc[j] + sh[j]);
-                o[j] = (acc ? o[j] : 0.f) + sc[j] * dpre + k1[j] * v[j] + k0[j];
-            }
-            V8<T>::st(dx + off, o);
-        }
-        return;
-    }
     __shared__ float s_sc[64], s_sh[64], s_k0[64], s_k1[64];
     {
         int c; float s1, s2;

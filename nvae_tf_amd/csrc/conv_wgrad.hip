@@ -484,8 +484,12 @@ static WgradPlan plan_conv_wgrad(const NvaeConvGeom* g, long scratch_floats, int
     const long flops = 2L * M * K * N;
     WgradPlan p;
     int KT, NTL;
-    if (flops >= (1L << 33) && N >= 128 && K >= 256) { p.cfg = 0; KT = 256; NTL = 128; }
-    else if (flops >= (1L << 32) && N >= 128 && K >= 128) { p.cfg = 1; KT = 128; NTL = 128; }
+    // the largest tile that still fills the chip: alone a layer needs the FLOPs for it, in a batch of n_layers
+    // same-shape layers (the towers) the tile count is multiplied by n_layers
+    const long nl = n_layers < 1 ? 1 : n_layers;
+    const long tiles0 = (long)cdiv(K, 256) * cdiv(N, 128) * nl, tiles1 = (long)cdiv(K, 128) * cdiv(N, 128) * nl;
+    if (N >= 128 && K >= 256 && (flops >= (1L << 33) || (nl > 1 && tiles0 >= 192))) { p.cfg = 0; KT = 256; NTL = 128; }
+    else if (N >= 128 && K >= 128 && (flops >= (1L << 32) || (nl > 1 && tiles1 >= 256))) { p.cfg = 1; KT = 128; NTL = 128; }
     else { p.cfg = 2; KT = 64; NTL = 64; }
     p.n_tiles = cdiv(N, NTL);
     p.tiles = cdiv(K, KT) * p.n_tiles;
