@@ -562,6 +562,11 @@ __global__ __launch_bounds__(WM * 128) void k_conv_halo(
             glds16(p, lds_base + (unsigned)(2 * A_CHUNKS + slot * B_CHUNKS + NT * j + wave * 64) * 16u);
         }
     };
+    auto issue_b_part = [&](int slot, int cc, int tap, int j) {      // j: compile-time after unrolling
+        const long k = (long)tap * g.Cin + (long)cc * CCH;
+        const void* p = nv[j] ? (const void*)(bp_[j] + k) : (const void*)zeros;
+        glds16(p, lds_base + (unsigned)(2 * A_CHUNKS + slot * B_CHUNKS + NT * j + wave * 64) * 16u);
+    };
 
     f32x4 acc[MI][NI];
 #pragma unroll
@@ -596,6 +601,40 @@ __global__ __launch_bounds__(WM * 128) void k_conv_halo(
     for (int i = 0; i < A_PASSES; ++i) issue_a(0, 0, i);
     issue_b(0, 0, 0);
     int cc = 0, tap = 0;
+    // bf16, 8 waves: PING-PONG.  A SIMD hosts waves w and w + 4.  If all eight leave the per-step barrier together,
+    // both waves of a SIMD read LDS at the same time (matrix pipe idle) and then fight for the matrix pipe (each
+    // stalled half the time): measured 53-55 % MFMA-busy, 28 % of wave-cycles parked.  Here a step is
+    // [barrier R | 20 operand reads + this wave's share of the next DMA | barrier M | 48 MFMAs from registers] and
+    // waves 4-7 run ONE BARRIER behind waves 0-3 (they pass one extra barrier before the loop, waves 0-3 one after
+    // it): in every interval one wave of a SIMD issues MFMAs while the other reads.  Same code for both halves.
+    // Ring-slot lifetimes: B(s + 1) goes into the slot of B(s - 1), whose last reader (a lagging wave) finished
+    // before the leading waves' barrier R of step s, the first barrier after which anyone issues that DMA; every
+    // wave waits for its own DMA before EVERY barrier, so B(s + 1) is complete before the leading waves' barrier R
+    // of step s + 1 (the lagging waves' barrier M of step s).
+    constexpr bool PINGPONG = sizeof(T) == 2 && WM * WN == 8;
+    const bool lag = PINGPONG && wave >= 4;
+    // prefetch(q): what step q's leading waves issue - the weight tile of step q + 1 and, during the first taps of a
+    // chunk, one pass of the next chunk's halo.  Leading waves call prefetch(s) in their read interval of step s
+    // (after barrier R of step s: the lagging waves finished reading that slot in the interval before).  Lagging
+    // waves call prefetch(s + 1) after THEIR barrier M of step s - the same point in time - so that their DMA
+    // also has a whole MFMA phase to land before their next loop-top wait (they are the last to pass a barrier
+    // before the leading waves read the tile).
+    auto prefetch = [&](int q, int tapq, int ccq) {
+        if (q >= S) return;
+        int ntap = tapq + 1, ncc_ = ccq;
+        if (ntap == TAPS) { ntap = 0; ++ncc_; }
+        if (q + 1 < S) issue_b((q + 1) & 1, ncc_, ntap);
+        if (tapq < A_PASSES && ccq + 1 < ncc) {
+#pragma unroll
+            for (int i = 0; i < A_PASSES; ++i)
+                if (i == tapq) issue_a((ccq + 1) & 1, ccq + 1, i);
+        }
+    };
+    if (lag) {
+        prefetch(0, 0, 0);
+        wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+    }
     for (int s = 0; s < S; ++s) {
         wait_vmcnt<0>();
         if constexpr (PRE) {
@@ -613,39 +652,66 @@ __global__ __launch_bounds__(WM * 128) void k_conv_halo(
         }
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        {   // prefetch: next weight tile, and one pass of the next chunk's halo
-            int ntap = tap + 1, ncc_ = cc;
-            if (ntap == TAPS) { ntap = 0; ++ncc_; }
-            if (s + 1 < S) issue_b((s + 1) & 1, ncc_, ntap);
-            if (tap < A_PASSES && cc + 1 < ncc) {
-#pragma unroll
-                for (int i = 0; i < A_PASSES; ++i)
-                    if (i == tap) issue_a((cc + 1) & 1, cc + 1, i);
-            }
-        }
         const uint4* abuf = lds + (cc & 1) * A_CHUNKS;
         const uint4* bbuf = lds + 2 * A_CHUNKS + (s & 1) * B_CHUNKS;
         const int kh = tap / KS, kw = tap - kh * KS;
+        int tap1 = tap + 1, cc1 = cc;
+        if (tap1 == TAPS) { tap1 = 0; ++cc1; }
+        if constexpr (PINGPONG) {
+            uint4 af[2][MI], bf[2][NI];
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            uint4 af[MI], bf[NI];
+            for (int h = 0; h < 2; ++h) {
 #pragma unroll
-            for (int i = 0; i < MI; ++i) {
-                const int hrow = (wm * MI + i + kh) * HP + kw + fr;
-                af[i] = abuf[hrow * 8 + ((h * 4 + fq) ^ (hrow & 7))];
+                for (int i = 0; i < MI; ++i) {
+                    const int hrow = (wm * MI + i + kh) * HP + kw + fr;
+                    af[h][i] = abuf[hrow * 8 + ((h * 4 + fq) ^ (hrow & 7))];
+                }
+#pragma unroll
+                for (int j = 0; j < NI; ++j) {
+                    const int r = wn * (BN / WN) + j * 16 + fr;
+                    bf[h][j] = bbuf[r * 8 + ((h * 4 + fq) ^ (r & 7))];
+                }
             }
+            __builtin_amdgcn_sched_barrier(0);
+            if (!lag) prefetch(s, tap, cc);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            // (the lagging waves issue their DMA share at the head of their MFMA interval: it must be waited for one
+            // barrier earlier than the leading waves' share.  Spreading the DMA instructions between the MFMAs of
+            // both halves measured 223 us against 171: the fences and M0 writes break the MFMA stream.)
+            if (lag) prefetch(s + 1, tap1, cc1);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int j = 0; j < NI; ++j) {
-                const int r = wn * (BN / WN) + j * 16 + fr;
-                bf[j] = bbuf[r * 8 + ((h * 4 + fq) ^ (r & 7))];
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NI; ++j) mfma_step<T>(af[h][i], bf[h][j], acc[i][j]);
+        } else {
+            prefetch(s, tap, cc);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                uint4 af[MI], bf[NI];
+#pragma unroll
+                for (int i = 0; i < MI; ++i) {
+                    const int hrow = (wm * MI + i + kh) * HP + kw + fr;
+                    af[i] = abuf[hrow * 8 + ((h * 4 + fq) ^ (hrow & 7))];
+                }
+#pragma unroll
+                for (int j = 0; j < NI; ++j) {
+                    const int r = wn * (BN / WN) + j * 16 + fr;
+                    bf[j] = bbuf[r * 8 + ((h * 4 + fq) ^ (r & 7))];
+                }
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NI; ++j) mfma_step<T>(af[i], bf[j], acc[i][j]);
             }
-#pragma unroll
-            for (int i = 0; i < MI; ++i)
-#pragma unroll
-                for (int j = 0; j < NI; ++j) mfma_step<T>(af[i], bf[j], acc[i][j]);
         }
-        if (++tap == TAPS) { tap = 0; ++cc; }
+        tap = tap1; cc = cc1;
     }
+    if (PINGPONG && !lag) { wait_vmcnt<0>(); __builtin_amdgcn_s_barrier(); }
     int ticket = 0;
     conv_epilogue<T, BM, BN, WM, WN, BNBWD>(acc, (float*)lds, g, bias, residual, out, out_f32, bp, bn, stats, vec_epi,
                                             [&](int r) -> long { return ((long)b * H + py0 + (r >> 4)) * W + px0 + (r & 15); }, be,

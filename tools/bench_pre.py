@@ -20,7 +20,7 @@ for (B, H, ci, co, k) in SHAPES:
     g = geom(B, H, ci, co, k)
     x = torch.randn(B, H, H, ci, device=dev).bfloat16()
     w = (torch.randn(co, k * k * ci, device=dev) * 0.05).bfloat16()
-    out = torch.empty(B, H, H, co, device=dev, dtype=torch.bfloat16)
+    out = torch.empty(B, H, H, co, device=dev, dtype=torch.float32)     # (large enough for either output dtype)
     act = torch.empty_like(x)
     S = lib.nvae_conv_gemm_stats_rows(L.BF16, C.byref(g))
     slab = torch.zeros(S, 2, co, device=dev)
@@ -55,4 +55,13 @@ for (B, H, ci, co, k) in SHAPES:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(); gr.replay(); e1.record(); torch.cuda.synchronize()
             res[name].append(e0.elapsed_time(e1) * 1000 / 20)
+    fn = arms["plain"]
+    for _ in range(3):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20):
+        fn()
+    e1.record(); torch.cuda.synchronize()
+    res["plain(eager)"] = [e0.elapsed_time(e1) * 1000 / 20]
     print(f"B{B} {H}x{H} {k}x{k} {ci}->{co}: " + "  ".join(f"{n} {sorted(v)[len(v)//2]:.1f}" for n, v in res.items()), flush=True)
