@@ -115,6 +115,9 @@ int nvae_conv_gemm_ex(int dtype, const NvaeConvGeom* g, const void* src, const v
                       const float* bias, const void* residual, void* out, int out_f32, float* stats,
                       const NvaeConvPre* pre, const NvaeBnFin* fin, void* stream);
 int nvae_conv_gemm_pre_max_cin(int dtype, const NvaeConvGeom* g);
+/* Tuning hook (tools/tune_conv.py): 0 = the launcher's own tile choice (default), 1..7 = force one tile family of
+ * the generic implicit-GEMM kernel for plain launches.  Process-wide; not for production use.       */
+int nvae_conv_gemm_force_tile(int tile);
 /* nvae_conv_gemm used as the DATA GRADIENT of a conv whose input was y = act(BN(x)) (the BNSwishConv /
  * ConvBNSwish pairs, encoder.py:91-98, decoder.py:125-135, postprocess.py:84-107): `out` receives dy
  * as usual and the epilogue additionally reduces dpre = dy * act'(scale*x + shift) against the same

@@ -66,6 +66,7 @@ _SIGS = {
     "nvae_conv_gemm": [_i, _G, _p, _p, _i, _p, _p, _p, _i, _p],
     "nvae_conv_gemm_ex": [_i, _G, _p, _p, _i, _p, _p, _p, _i, _p, _p, _p],
     "nvae_conv_gemm_pre_max_cin": None,
+    "nvae_conv_gemm_force_tile": None,
     "nvae_conv_gemm_bnbwd": [_i, _p, _p, _p, _i, _p, _p, _p, _p],
     "nvae_conv_wgrad_scratch": None,
     "nvae_conv_wgrad_scratch_n": None,
@@ -160,6 +161,8 @@ def load():
     lib.nvae_dwconv5_stats_rows.argtypes = [_i, _i, _i, _i, _i]
     lib.nvae_conv_gemm_stats_rows.restype = C.c_int
     lib.nvae_conv_gemm_stats_rows.argtypes = [_i, _G]
+    lib.nvae_conv_gemm_force_tile.restype = C.c_int
+    lib.nvae_conv_gemm_force_tile.argtypes = [_i]
     lib.nvae_conv_gemm_pre_max_cin.restype = C.c_int
     lib.nvae_conv_gemm_pre_max_cin.argtypes = [_i, _G]
     lib.nvae_conv_wgrad_scratch.restype = C.c_long

@@ -736,17 +736,41 @@ static bool conv_halo_ok(int dtype, const NvaeConvGeom* g) {
            (long)g->B * (g->Hin / 16) * (g->Win / 16) * cdiv(N, 192) >= 64;
 }
 
-static int conv_gemm_bm(int dtype, const NvaeConvGeom* g) {
-    // M-tile height the launcher will pick (must match launch_conv_gemm)
-    if (conv_halo_ok(dtype, g)) return 256;
+// Tile family of the generic kernel for a geometry (tools/tune_conv.py sweeps them on the tower shapes):
+//  1: 256x192 (2-deep ring)  2: 128x192  3: 128x128  4: 128x64  5: 32x64, 128-deep steps  6: 64x64, 128-deep  7: 64x64
+static int conv_tile_family(const NvaeConvGeom* g) {
     const int M = g->B * g->Hout * g->Wout, K = g->KH * g->KW * g->Cin, N = g->Cout;
     const long big_tiles = (long)cdiv(M, 128) * cdiv(N, 128);
     const long w192 = (long)cdiv(N, 192) * 192, w128 = (long)cdiv(N, 128) * 128, w64 = (long)cdiv(N, 64) * 64;
-    if ((long)cdiv(M, 256) * cdiv(N, 192) >= 224 && w192 <= w128 && w192 <= w64 && K >= 1024) return 256;
-    if (big_tiles >= 192) return 128;
-    if (K >= 512 && (long)cdiv(M, 64) * cdiv(N, 64) <= 160) return 32;
-    return 64;
+    // the FLOP-dominant layers: 256 x 192 tile (112 FLOP per staged byte), 2-deep ring (112 KB); also the
+    // single-K-step 1x1 convs on >= 16x16 images, which are bound by their output stores (fewer, fatter epilogues)
+    if ((long)cdiv(M, 256) * cdiv(N, 192) >= 224 && w192 <= w128 && w192 <= w64 && (K >= 1024 || K <= 64)) return 1;
+    // large problems: 128-row tiles, 8 waves; N tile with the least padding (ties -> larger).  With a short K loop
+    // (K < 512) the 128-row tiles need twice the tiles to beat 64 x 64 (256 -> 1536 at 4x4: 10.2 vs 7.7 us)
+    if (big_tiles >= (K < 512 ? 256 : 192)) {
+        if (w192 <= w128 && w192 <= w64) return 2;
+        if (w128 <= w64) return 3;
+        return 4;
+    }
+    if (K >= 512) {
+        // small M: latency-bound K loop -> 8 waves, 128-deep ring steps (half the barriers).  These are bound by the
+        // bytes each CU can pull in ((BM + BN) * K * 2 per workgroup at ~22 B/cycle/CU): when 64-row tiles leave CUs
+        // idle, 32-row tiles use the whole chip and cut the per-CU bytes by 25 %
+        return (long)cdiv(M, 64) * cdiv(N, 64) <= 160 ? 5 : 6;
+    }
+    return 7;
 }
+
+static int conv_gemm_bm(int dtype, const NvaeConvGeom* g) {
+    // M-tile height the launcher will pick
+    if (conv_halo_ok(dtype, g)) return 256;
+    static const int bm[8] = {0, 256, 128, 128, 128, 32, 64, 64};
+    return bm[conv_tile_family(g)];
+}
+
+// tuning hook (tools/tune_conv.py): 0 = the launcher's own choice, 1..7 = force a tile family of k_conv_gemm2
+static int g_force_tile = 0;
+extern "C" int nvae_conv_gemm_force_tile(int t) { g_force_tile = t; return NVAE_OK; }
 
 template <typename T>
 static int launch_conv_gemm(const NvaeConvGeom* g, const void* src, const void* wT, int w_ld,
@@ -797,23 +821,14 @@ static int launch_conv_gemm(const NvaeConvGeom* g, const void* src, const void* 
       else LAUNCH2F(BM_, BN_, WM_, WN_, ST_, BKC_, false, false) }
     // Large problems: 128-row tiles, 8 waves; N tile with the least padding (ties -> larger).
     // Small problems (few tiles): 64 x 64 tiles, 4 waves, so that the grid covers the chip.
-    const long big_tiles = (long)cdiv(M, 128) * cdiv(N, 128);
-    const long w192 = (long)cdiv(N, 192) * 192, w128 = (long)cdiv(N, 128) * 128, w64 = (long)cdiv(N, 64) * 64;
-    if ((long)cdiv(M, 256) * cdiv(N, 192) >= 224 && w192 <= w128 && w192 <= w64 && K >= 1024) {
-        // the FLOP-dominant layers: 256 x 192 tile (112 FLOP per staged byte), 2-deep ring (112 KB)
-        LAUNCH2(256, 192, 4, 2, 2, 8)
-    } else if (big_tiles >= 192) {
-        if (w192 <= w128 && w192 <= w64) LAUNCH2(128, 192, 2, 4, 3, 8)
-        else if (w128 <= w64) LAUNCH2(128, 128, 2, 4, 3, 8)
-        else LAUNCH2(128, 64, 4, 2, 3, 8)
-    } else if (K >= 512) {
-        // small M: latency-bound K loop -> 8 waves, 128-deep ring steps (half the barriers)
-        // these are bound by the bytes each CU can pull in ((BM + BN) * K * 2 per workgroup at ~22 B/cycle/CU):
-        // when 64-row tiles leave CUs idle, 32-row tiles use the whole chip and cut the per-CU bytes by 25 %
-        if ((long)cdiv(M, 64) * cdiv(N, 64) <= 160) LAUNCH2(32, 64, 2, 4, 3, 16)
-        else LAUNCH2(64, 64, 2, 4, 3, 16)
-    } else {
-        LAUNCH2(64, 64, 2, 2, 3, 8)
+    switch ((g_force_tile && !be.x) ? g_force_tile : conv_tile_family(g)) {
+        case 1: LAUNCH2(256, 192, 4, 2, 2, 8) break;
+        case 2: LAUNCH2(128, 192, 2, 4, 3, 8) break;
+        case 3: LAUNCH2(128, 128, 2, 4, 3, 8) break;
+        case 4: LAUNCH2(128, 64, 4, 2, 3, 8) break;
+        case 5: LAUNCH2(32, 64, 2, 4, 3, 16) break;
+        case 6: LAUNCH2(64, 64, 2, 4, 3, 16) break;
+        default: LAUNCH2(64, 64, 2, 2, 3, 8) break;
     }
 #undef LAUNCH2
 #undef LAUNCH2F
