@@ -185,7 +185,15 @@ int nvae_dwconv5_wgrad(int dtype, const void* x, const void* dy, float* dw, floa
 
 /* ---- BatchNormalization(momentum=.05, eps=1e-5) (+Swish), encoder.py:91-103, decoder.py:125-146,
  *      postprocess.py:71,84,107-108, preprocess.py:88-89, common.py:148,165-166 ------------------- */
-/* Row splits S used by the [rows, C] reductions; slabs passed as `partials` hold S*2*C floats.  */
+/* STATISTICS SLABS.  Every slab is [rows][2][C]: (sum x, sum x^2) for the forward statistics, (sum dpre,
+ * sum dpre*x) for the backward sums.  Its ELEMENT TYPE follows the activation dtype of the call that writes or
+ * reads it: float for NVAE_BF16, DOUBLE for NVAE_F32 (the parity path: E[x^2]-E[x]^2 and sum dpre*x - mean*sum dpre
+ * cancel 8-9 bits where |mean| >> std, e.g. on the depthwise-conv outputs in front of decoder.py:131, and f32
+ * sums - or just their run-to-run order under atomics - moved the C2 loss by up to 2.6e-3).  Slabs declared
+ * `float*` below are therefore S*2*C floats or S*2*C doubles; entry points that only read a slab take the
+ * dtype of its producer as their first argument.  Slabs that producers ADD into (conv / depthwise / fused-SE
+ * epilogues) must be zeroed.
+ * Row splits S used by the strip reductions (nvae_bn_stats, nvae_bn_bwd_reduce):                  */
 int nvae_reduce_splits(long rows, int C);
 /* partials[S][2][C] <- per-split (sum x, sum x^2).  No atomics, nothing needs zeroing.
  * dtype == NVAE_F32: the slab holds S*2*C DOUBLES (sums accumulated and combined in f64: E[x^2]-E[x]^2
@@ -198,7 +206,7 @@ int nvae_bn_finalize(int dtype, const float* partials, long rows, int C, const f
                      float* running_mean, float* running_var, float momentum, float eps,
                      float* scale, float* shift, float* mean, float* invstd, void* stream);
 /* as nvae_bn_finalize for a slab with an explicit number of row splits S (conv-epilogue statistics) */
-int nvae_bn_finalize_s(const float* partials, int S, long rows, int C, const float* gamma,
+int nvae_bn_finalize_s(int dtype, const float* partials, int S, long rows, int C, const float* gamma,
                        const float* beta, float* running_mean, float* running_var, float momentum,
                        float eps, float* scale, float* shift, float* mean, float* invstd, void* stream);
 /* nvae_bn_stats + nvae_bn_finalize in ONE launch: the last workgroup of each 64-channel strip sums the
@@ -234,7 +242,7 @@ int nvae_bn_bwd_reduce(int dtype, const void* x, const void* dy, long rows, int 
 /* dgamma += sum dpre*xhat, dbeta += sum dpre; k0k1[2][C] = coefficients of
  * dx = scale*dpre + k1*x + k0 (the batch-statistics terms of the BN gradient; zero when `frozen`,
  * i.e. the layer normalised with moving statistics).                                            */
-int nvae_bn_bwd_finalize(const float* partials, long rows, int C, const float* scale,
+int nvae_bn_bwd_finalize(int dtype, const float* partials, long rows, int C, const float* scale,
                          const float* mean, const float* invstd, float* dgamma, float* dbeta,
                          float* k0k1, int frozen, void* stream);
 /* nvae_bn_bwd_reduce + nvae_bn_bwd_finalize in ONE launch (counters as for nvae_bn_stats_fin).    */
@@ -244,7 +252,7 @@ int nvae_bn_bwd_reduce_fin(int dtype, const void* x, const void* dy, long rows, 
                            float* dgamma, float* dbeta, float* k0k1, int frozen, void* stream);
 /* as nvae_bn_bwd_finalize for a slab with S row splits (S = nvae_conv_gemm_stats_rows for the slab that
  * nvae_conv_gemm_bnbwd leaves when it is given no counters)                                        */
-int nvae_bn_bwd_finalize_s(const float* partials, int S, long rows, int C, const float* scale,
+int nvae_bn_bwd_finalize_s(int dtype, const float* partials, int S, long rows, int C, const float* scale,
                            const float* mean, const float* invstd, float* dgamma, float* dbeta,
                            float* k0k1, int frozen, void* stream);
 int nvae_bn_bwd_apply(int dtype, const void* x, const void* dy, void* dx, long rows, int C,
@@ -412,12 +420,16 @@ typedef struct NvaeConvDesc {
     int wf_ld, wd_ld;
     int idx;           /* position in per-matrix scratch arrays                                  */
     int blk_off;       /* first workgroup of this matrix; a workgroup owns 16 consecutive k rows  */
+    long long p_off;   /* this matrix's [ceil(K/16)][Cout] block in `colpart` (nvae_sn_power_iter)   */
 } NvaeConvDesc;
 /* One power iteration per matrix: v = l2n(u W^T); u' = l2n(v W); sigma = v W u'^T.  Writes u' into
- * sn_state and 1/sigma into inv_sigma; W itself is rescaled by nvae_weight_prep.                 */
+ * sn_state and 1/sigma into inv_sigma; W itself is rescaled by nvae_weight_prep.  Every sum is taken in a
+ * fixed order (no atomics): sigma is bit-reproducible, so data-parallel replicas do not drift.
+ * colpart: scratch of sum_i ceil(K_i/16)*Cout_i floats (NvaeConvDesc.p_off); w2: scratch laid out like
+ * sn_state.  Neither needs zeroing.                                                                */
 int nvae_sn_power_iter(float* params, const NvaeConvDesc* descs /*device*/, int n, int total_blocks,
-                       float* sn_state, float* sn_scratch_t, float* nt2 /*[n] zeroed*/,
-                       float* w2 /*[sum Cout] zeroed*/, float* inv_sigma /*[n]*/, void* stream);
+                       float* sn_state, float* sn_scratch_t, float* colpart, float* w2,
+                       float* inv_sigma /*[n]*/, void* stream);
 /* W *= inv_sigma[i] in place (skipped if inv_sigma NULL) and (re)write both compute copies.      */
 int nvae_weight_prep(int dtype, float* params, const NvaeConvDesc* descs, int n, int total_blocks,
                      const float* inv_sigma, void* wcopies, void* stream);

@@ -54,7 +54,7 @@ class ConvDesc(C.Structure):
     _fields_ = [("w_off", C.c_longlong), ("wf_off", C.c_longlong), ("wd_off", C.c_longlong),
                 ("u_off", C.c_int), ("t_off", C.c_int), ("K", C.c_int), ("Cout", C.c_int),
                 ("Cin", C.c_int), ("taps", C.c_int), ("wf_ld", C.c_int), ("wd_ld", C.c_int),
-                ("idx", C.c_int), ("blk_off", C.c_int)]
+                ("idx", C.c_int), ("blk_off", C.c_int), ("p_off", C.c_longlong)]
 
 
 _p, _i, _l, _f = C.c_void_p, C.c_int, C.c_long, C.c_float
@@ -82,7 +82,7 @@ _SIGS = {
     "nvae_dwconv5_stats_rows": None,
     "nvae_bn_stats": [_i, _p, _l, _i, _p],
     "nvae_bn_finalize": [_i, _p, _l, _i, _p, _p, _p, _p, _f, _f, _p, _p, _p, _p],
-    "nvae_bn_finalize_s": [_p, _i, _l, _i, _p, _p, _p, _p, _f, _f, _p, _p, _p, _p],
+    "nvae_bn_finalize_s": [_i, _p, _i, _l, _i, _p, _p, _p, _p, _f, _f, _p, _p, _p, _p],
     "nvae_bn_eval_prepare": [_p, _p, _p, _p, _i, _f, _p, _p, _p, _p],
     "nvae_bn_apply": [_i, _p, _p, _l, _i, _p, _p, _i],
     "nvae_bn_bwd_reduce": [_i, _p, _p, _l, _i, _p, _p, _i, _p],
@@ -90,8 +90,8 @@ _SIGS = {
     "nvae_bn_bwd_apply_fin": [_i, _p, _p, _p, _l, _i, _p, _i, _p, _p, _p, _p, _p, _p, _i, _i, _i],
     "nvae_bn_stats_fin": [_i, _p, _l, _i, _p, _p, _p, _p, _p, _p, _f, _f, _p, _p, _p, _p],
     "nvae_bn_bwd_reduce_fin": [_i, _p, _p, _l, _i, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p, _i],
-    "nvae_bn_bwd_finalize": [_p, _l, _i, _p, _p, _p, _p, _p, _p, _i],
-    "nvae_bn_bwd_finalize_s": [_p, _i, _l, _i, _p, _p, _p, _p, _p, _p, _i],
+    "nvae_bn_bwd_finalize": [_i, _p, _l, _i, _p, _p, _p, _p, _p, _p, _i],
+    "nvae_bn_bwd_finalize_s": [_i, _p, _i, _l, _i, _p, _p, _p, _p, _p, _p, _i],
     "nvae_bn_bwd_apply": [_i, _p, _p, _p, _l, _i, _p, _p, _p, _i, _i],
     "nvae_se_pool": [_i, _p, _i, _i, _i, _p],
     "nvae_se_gate": [_p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p],

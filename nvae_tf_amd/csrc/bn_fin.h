@@ -27,7 +27,6 @@ struct BnFinArgs {
     // backward (sum dpre, sum dpre*x -> dgamma, dbeta, k0, k1); reads scale/mean/invstd above
     float* dgamma; float* dbeta; float* k0k1;
     int frozen;
-    int slab_f64;                  // forward statistics slab holds doubles (k_stripreduce on f32 tensors, below)
 };
 
 // All threads of the workgroup call this after their partial stores.  Returns true (uniformly) in
@@ -78,18 +77,26 @@ __device__ __forceinline__ bool bn_was_last(int* counter, int ticket, int contri
 // neither a finalize launch nor a last-arriver hand-off is needed; the workgroup the caller elects (`publish`)
 // also writes the table for the backward pass and updates the moving statistics.
 struct BnFromSlab {
-    const float* slab; int rows;         // nullptr: scale / shift below are already final (inputs)
+    const void* slab; int rows;          // nullptr: scale / shift below are already final (inputs)
     float inv_n, eps, momentum;
     const float* gamma; const float* beta;
     float* rm; float* rv;
     float* scale; float* shift; float* mean; float* invstd;
 };
+// F64: the slab holds doubles (the f32 activation path, see "statistics precision" below)
+template <bool F64>
 __device__ __forceinline__ void bn_coef(const BnFromSlab& a, int C, int c, bool publish, float& sc, float& sh) {
     if (a.slab == nullptr) { sc = a.scale[c]; sh = a.shift[c]; return; }
-    float s1 = 0.f, s2 = 0.f;
-    for (int r = 0; r < a.rows; ++r) { s1 += a.slab[((long)r * 2) * C + c]; s2 += a.slab[((long)r * 2 + 1) * C + c]; }
-    const float m = s1 * a.inv_n;
-    const float var = fmaxf(s2 * a.inv_n - m * m, 0.f);
+    double s1 = 0.0, s2 = 0.0;
+    for (int r = 0; r < a.rows; ++r) {
+        if constexpr (F64) {
+            s1 += ((const double*)a.slab)[((long)r * 2) * C + c]; s2 += ((const double*)a.slab)[((long)r * 2 + 1) * C + c];
+        } else {
+            s1 += ((const float*)a.slab)[((long)r * 2) * C + c]; s2 += ((const float*)a.slab)[((long)r * 2 + 1) * C + c];
+        }
+    }
+    const double md = s1 * (double)a.inv_n;
+    const float m = (float)md, var = (float)fmax(s2 * (double)a.inv_n - md * md, 0.0);
     const float is = rsqrtf(var + a.eps);
     sc = a.gamma[c] * is;
     sh = a.beta[c] - m * sc;
@@ -145,13 +152,7 @@ __device__ __forceinline__ bool bn_slab_sum64(const float* partials, int S, int 
     return true;
 }
 
-// The same for a slab of DOUBLES.  The f32 activation path takes the statistics of tensors that no kernel
-// epilogue produces (notably the depthwise-conv outputs in front of bn3, decoder.py:131-132) from
-// k_stripreduce, and there E[x^2] - E[x]^2 in f32 is not good enough: |mean| / std reaches 15-19 on those
-// layers at initialisation, i.e. the subtraction cancels 8-9 bits, and through the ~330 layers of the C2
-// configuration that alone tripled the distance to the fp64 oracle (measured: the f32 oracle with this
-// single-pass variance is 3x further from fp64 than with a two-pass one).  Sums of x and x^2 accumulated and
-// combined in f64 make the single pass exact to f32 rounding of the inputs.
+// The same for a slab of DOUBLES (the f32 activation path: "statistics precision" below).
 __device__ __forceinline__ bool bn_slab_sum64_f64(const double* partials, int S, int C, int cbase, int& c,
                                                   double& s1, double& s2) {
     __shared__ double smd[4][2][64];
@@ -172,7 +173,28 @@ __device__ __forceinline__ bool bn_slab_sum64_f64(const double* partials, int S,
     return true;
 }
 
-__device__ __forceinline__ void bn_fin_fwd_channel_f64(const BnFinArgs& a, int c, double s1, double s2) {
+// ---- statistics precision -------------------------------------------------------------------------------
+// Every slab is [rows][2][C]: (sum x, sum x^2) forward, (sum dpre, sum dpre*x) backward.  On the bf16 activation path
+// its elements are floats.  On the f32 path (the parity path) they are DOUBLES and the producers accumulate in f64:
+// E[x^2] - E[x]^2 and sum dpre*x - mean * sum dpre are differences of nearly equal numbers when |mean| >> std
+// (15-19 on the depthwise-conv outputs in front of bn3 at initialisation), and through the ~330 layers of the C2
+// configuration an f32 rounding of those sums - or merely a different ORDER of the f32 atomic adds from run to
+// run - moved the loss by up to 2.6e-3 (5 nats) between runs and three times further from the fp64 oracle than
+// the PyTorch-CPU f32 run of the same model.  All finalize arithmetic below is done in double either way.
+template <bool F64>
+__device__ __forceinline__ bool bn_slab_sum64_t(const void* partials, int S, int C, int cbase, int& c, double& s1,
+                                                double& s2) {
+    if constexpr (F64) {
+        return bn_slab_sum64_f64((const double*)partials, S, C, cbase, c, s1, s2);
+    } else {
+        float a = 0.f, b = 0.f;
+        const bool ok = bn_slab_sum64((const float*)partials, S, C, cbase, c, a, b);
+        s1 = a; s2 = b;
+        return ok;
+    }
+}
+
+__device__ __forceinline__ void bn_fin_fwd_channel(const BnFinArgs& a, int c, double s1, double s2) {
     const double md = s1 * (double)a.inv_n;
     const double vd = fmax(s2 * (double)a.inv_n - md * md, 0.0);
     const float m = (float)md, var = (float)vd;
@@ -186,53 +208,42 @@ __device__ __forceinline__ void bn_fin_fwd_channel_f64(const BnFinArgs& a, int c
     a.rv[c] = a.rv[c] * a.momentum + var * (1.f - a.momentum);
 }
 
-__device__ __forceinline__ void bn_fin_fwd_channel(const BnFinArgs& a, int c, float s1, float s2) {
-    const float m = s1 * a.inv_n;
-    const float var = fmaxf(s2 * a.inv_n - m * m, 0.f);
-    const float is = rsqrtf(var + a.eps);
-    const float sc = a.gamma[c] * is;
-    a.scale[c] = sc;
-    a.shift[c] = a.beta[c] - m * sc;
-    a.mean[c] = m;
-    a.invstd[c] = is;
-    a.rm[c] = a.rm[c] * a.momentum + m * (1.f - a.momentum);
-    a.rv[c] = a.rv[c] * a.momentum + var * (1.f - a.momentum);
-}
-
 // dbeta = sum dpre; dgamma = invstd * (sum dpre*x - mean * sum dpre);
 // dx = scale*dpre + k1*x + k0 (k0 = k1 = 0 for frozen statistics).
-__device__ __forceinline__ void bn_fin_bwd_channel(const BnFinArgs& a, int C, int c, float s1, float s2) {
+__device__ __forceinline__ void bn_bwd_coefs(const BnFinArgs& a, int c, double s1, double s2, float& dg, float& k0,
+                                             float& k1) {
     const float m = a.mean[c], is = a.invstd[c], sc = a.scale[c];
-    const float dg = is * (s2 - m * s1);
+    dg = (float)((double)is * (s2 - (double)m * s1));
+    k1 = a.frozen ? 0.f : -sc * dg * is * a.inv_n;
+    k0 = a.frozen ? 0.f : (float)(-(double)sc * s1 * (double)a.inv_n) - k1 * m;
+}
+__device__ __forceinline__ void bn_fin_bwd_channel(const BnFinArgs& a, int C, int c, double s1, double s2) {
+    float dg, k0, k1;
+    bn_bwd_coefs(a, c, s1, s2, dg, k0, k1);
     a.dgamma[c] += dg;
-    a.dbeta[c] += s1;
-    const float k1 = a.frozen ? 0.f : -sc * dg * is * a.inv_n;
-    a.k0k1[c] = a.frozen ? 0.f : -sc * s1 * a.inv_n - k1 * m;
+    a.dbeta[c] += (float)s1;
+    a.k0k1[c] = k0;
     a.k0k1[C + c] = k1;
 }
 
-// Finalize `ngroups64` consecutive 64-channel groups starting at cbase (forward statistics).
-__device__ __forceinline__ void bn_fin_fwd(const BnFinArgs& a, const float* partials, int S, int C,
+// Finalize `ngroups64` consecutive 64-channel groups starting at cbase.
+template <bool F64>
+__device__ __forceinline__ void bn_fin_fwd(const BnFinArgs& a, const void* partials, int S, int C,
                                            int cbase, int ngroups64) {
     for (int g = 0; g < ngroups64; ++g) {
-        int c; float s1, s2;
-        if (bn_slab_sum64(partials, S, C, cbase + g * 64, c, s1, s2)) bn_fin_fwd_channel(a, c, s1, s2);
+        int c; double s1, s2;
+        if (bn_slab_sum64_t<F64>(partials, S, C, cbase + g * 64, c, s1, s2)) bn_fin_fwd_channel(a, c, s1, s2);
     }
 }
-// the same for a slab of doubles (k_stripreduce on f32 tensors); a separate function so that kernels which never
-// see such a slab do not carry its LDS
-__device__ __forceinline__ void bn_fin_fwd_f64(const BnFinArgs& a, const double* partials, int S, int C,
-                                               int cbase, int ngroups64) {
+template <bool F64>
+__device__ __forceinline__ void bn_fin_bwd(const BnFinArgs& a, const void* partials, int S, int C,
+                                           int cbase, int ngroups64) {
     for (int g = 0; g < ngroups64; ++g) {
-        int c; double d1, d2;
-        if (bn_slab_sum64_f64(partials, S, C, cbase + g * 64, c, d1, d2)) bn_fin_fwd_channel_f64(a, c, d1, d2);
+        int c; double s1, s2;
+        if (bn_slab_sum64_t<F64>(partials, S, C, cbase + g * 64, c, s1, s2)) bn_fin_bwd_channel(a, C, c, s1, s2);
     }
 }
 
-__device__ __forceinline__ void bn_fin_bwd(const BnFinArgs& a, const float* partials, int S, int C,
-                                           int cbase, int ngroups64) {
-    for (int g = 0; g < ngroups64; ++g) {
-        int c; float s1, s2;
-        if (bn_slab_sum64(partials, S, C, cbase + g * 64, c, s1, s2)) bn_fin_bwd_channel(a, C, c, s1, s2);
-    }
-}
+// slab element type of an activation type
+template <typename T> struct StatT { typedef float type; };
+template <> struct StatT<float> { typedef double type; };

@@ -18,9 +18,10 @@
 // MODE 2: per-image sum   q0 = x           (blockIdx.z = image, S = 1, direct store)
 // MODE 3: per-image sum   q0 = x*dy
 // MODE 4: column sum with leading dimension ld, q0 = x   (atomics, S small)
-// MODE 0 on f32 tensors accumulates and writes its slab in f64 (see bn_fin.h: bn_slab_sum64_f64)
+// MODE 0 / 1 on f32 tensors accumulate and write their slab in f64 (bn_fin.h "statistics precision")
 template <typename T, int MODE> struct StripAcc { typedef float type; };
 template <> struct StripAcc<float, 0> { typedef double type; };
+template <> struct StripAcc<float, 1> { typedef double type; };
 
 template <typename T, int MODE>
 __global__ __launch_bounds__(RED_THREADS) void k_stripreduce(
@@ -65,8 +66,8 @@ __global__ __launch_bounds__(RED_THREADS) void k_stripreduce(
                 for (int j = 0; j < 8; ++j) {
                     float dpre = g[j];
                     if (act == ACT_SWISH) dpre *= dswishf_(v[j] * sc[j] + sh[j]);
-                    acc[0][j] += dpre;
-                    acc[1][j] += dpre * v[j];
+                    acc[0][j] += (A)dpre;
+                    acc[1][j] += (A)dpre * (A)v[j];
                 }
             } else if (MODE == 3) {
                 float g[8];
@@ -113,9 +114,8 @@ __global__ __launch_bounds__(RED_THREADS) void k_stripreduce(
         // fused finalize: the last of this strip's gridDim.y workgroups turns the slabs into coefficients
         if (fin.counter == nullptr) return;
         if (!bn_last_arriver(fin.counter + blockIdx.x, (int)gridDim.y)) return;
-        if constexpr (MODE == 0 && sizeof(A) == 8) bn_fin_fwd_f64(fin, (const double*)out, (int)gridDim.y, C, blockIdx.x * 64, 1);
-        else if constexpr (MODE == 0) bn_fin_fwd(fin, out, (int)gridDim.y, C, blockIdx.x * 64, 1);
-        else bn_fin_bwd(fin, out, (int)gridDim.y, C, blockIdx.x * 64, 1);
+        if constexpr (MODE == 0) bn_fin_fwd<sizeof(A) == 8>(fin, out, (int)gridDim.y, C, blockIdx.x * 64, 1);
+        else bn_fin_bwd<sizeof(A) == 8>(fin, out, (int)gridDim.y, C, blockIdx.x * 64, 1);
     }
 }
 
@@ -160,51 +160,38 @@ extern "C" int nvae_bn_stats(int dtype, const void* x, long rows, int C, float* 
     return NVAE_OK;
 }
 
-__global__ void k_bn_finalize(const float* __restrict__ partials, int S, float inv_n, int C,
-                              const float* __restrict__ gamma, const float* __restrict__ beta,
-                              float* rm, float* rv, float momentum, float eps, float* scale,
-                              float* shift, float* mean, float* invstd, int slab_f64) {
-    int c;
-    float m, var;
-    if (slab_f64) {
-        double d1, d2;
-        if (!bn_slab_sum64_f64((const double*)partials, S, C, blockIdx.x * 64, c, d1, d2)) return;
-        const double md = d1 * (double)inv_n;
-        m = (float)md;
-        var = (float)fmax(d2 * (double)inv_n - md * md, 0.0);
-    } else {
-        float s1, s2;
-        if (!bn_slab_sum64(partials, S, C, blockIdx.x * 64, c, s1, s2)) return;
-        m = s1 * inv_n;
-        var = fmaxf(s2 * inv_n - m * m, 0.f);
-    }
-    float is = rsqrtf(var + eps);
-    float sc = gamma[c] * is;
-    scale[c] = sc;
-    shift[c] = beta[c] - m * sc;
-    mean[c] = m;
-    invstd[c] = is;
-    rm[c] = rm[c] * momentum + m * (1.f - momentum);
-    rv[c] = rv[c] * momentum + var * (1.f - momentum);
+template <bool F64>
+__global__ void k_bn_finalize(const void* __restrict__ partials, int S, int C, BnFinArgs a) {
+    int c; double s1, s2;
+    if (bn_slab_sum64_t<F64>(partials, S, C, blockIdx.x * 64, c, s1, s2)) bn_fin_fwd_channel(a, c, s1, s2);
+}
+
+static void launch_bn_finalize(int dtype, const float* partials, int S, long rows, int C, const float* gamma,
+                               const float* beta, float* rm, float* rv, float momentum, float eps, float* scale,
+                               float* shift, float* mean, float* invstd, hipStream_t s) {
+    BnFinArgs f{};
+    f.inv_n = 1.0f / (float)rows; f.gamma = gamma; f.beta = beta; f.rm = rm; f.rv = rv; f.momentum = momentum;
+    f.eps = eps; f.scale = scale; f.shift = shift; f.mean = mean; f.invstd = invstd;
+    if (dtype == NVAE_F32) hipLaunchKernelGGL(k_bn_finalize<true>, cdiv(C, 64), 256, 0, s, (const void*)partials, S, C, f);
+    else hipLaunchKernelGGL(k_bn_finalize<false>, cdiv(C, 64), 256, 0, s, (const void*)partials, S, C, f);
 }
 
 extern "C" int nvae_bn_finalize(int dtype, const float* partials, long rows, int C, const float* gamma,
                                 const float* beta, float* rm, float* rv, float momentum, float eps,
                                 float* scale, float* shift, float* mean, float* invstd, void* stream) {
     NVAE_REQUIRE(rows > 0 && C > 0, "bn_finalize: bad shape");
-    const int S = nvae_reduce_splits(rows, C);
-    hipLaunchKernelGGL(k_bn_finalize, cdiv(C, 64), 256, 0, (hipStream_t)stream, partials, S, 1.0f / (float)rows,
-                       C, gamma, beta, rm, rv, momentum, eps, scale, shift, mean, invstd, dtype == NVAE_F32);
+    launch_bn_finalize(dtype, partials, nvae_reduce_splits(rows, C), rows, C, gamma, beta, rm, rv, momentum, eps, scale,
+                       shift, mean, invstd, (hipStream_t)stream);
     NVAE_LAUNCH_CHECK("bn_finalize");
     return NVAE_OK;
 }
 
-extern "C" int nvae_bn_finalize_s(const float* partials, int S, long rows, int C, const float* gamma,
+extern "C" int nvae_bn_finalize_s(int dtype, const float* partials, int S, long rows, int C, const float* gamma,
                                   const float* beta, float* rm, float* rv, float momentum, float eps,
                                   float* scale, float* shift, float* mean, float* invstd, void* stream) {
     NVAE_REQUIRE(rows > 0 && C > 0 && S > 0, "bn_finalize_s: bad shape");
-    hipLaunchKernelGGL(k_bn_finalize, cdiv(C, 64), 256, 0, (hipStream_t)stream, partials, S, 1.0f / (float)rows,
-                       C, gamma, beta, rm, rv, momentum, eps, scale, shift, mean, invstd, 0);
+    launch_bn_finalize(dtype, partials, S, rows, C, gamma, beta, rm, rv, momentum, eps, scale, shift, mean, invstd,
+                       (hipStream_t)stream);
     NVAE_LAUNCH_CHECK("bn_finalize_s");
     return NVAE_OK;
 }
@@ -221,7 +208,6 @@ extern "C" int nvae_bn_stats_fin(int dtype, const void* x, long rows, int C, flo
     BnFinArgs f{};
     f.counter = counters; f.inv_n = 1.0f / (float)rows; f.gamma = gamma; f.beta = beta; f.rm = rm; f.rv = rv;
     f.momentum = momentum; f.eps = eps; f.scale = scale; f.shift = shift; f.mean = mean; f.invstd = invstd;
-    f.slab_f64 = dtype == NVAE_F32;
     DISPATCH_T(dtype, launch_strip<T, 0>((const T*)x, nullptr, 1, rows, C, C, S, nullptr, nullptr, 0, partials, (hipStream_t)stream, &f);)
     NVAE_LAUNCH_CHECK("bn_stats_fin");
     return NVAE_OK;
@@ -300,30 +286,28 @@ extern "C" int nvae_bn_bwd_reduce(int dtype, const void* x, const void* dy, long
 
 // dbeta = sum dpre; dgamma = sum dpre*xhat = invstd * (sum dpre*x - mean * sum dpre).
 // dx = scale*(dpre - dbeta/N - xhat*dgamma/N) = scale*dpre + k1*x + k0.
-__global__ void k_bn_bwd_finalize(const float* __restrict__ partials, int S, float inv_n, int C,
-                                  const float* __restrict__ scale, const float* __restrict__ mean,
-                                  const float* __restrict__ invstd, float* dgamma, float* dbeta,
-                                  float* __restrict__ k0k1, int frozen) {
-    int c;
-    float s1, s2;
-    if (!bn_slab_sum64(partials, S, C, blockIdx.x * 64, c, s1, s2)) return;
-    const float m = mean[c], is = invstd[c], sc = scale[c];
-    const float dg = is * (s2 - m * s1);
-    dgamma[c] += dg;
-    dbeta[c] += s1;
-    // frozen (moving) statistics do not depend on the batch: dx = scale * dpre only
-    const float k1 = frozen ? 0.f : -sc * dg * is * inv_n;
-    k0k1[c] = frozen ? 0.f : -sc * s1 * inv_n - k1 * m;
-    k0k1[C + c] = k1;
+template <bool F64>
+__global__ void k_bn_bwd_finalize(const void* __restrict__ partials, int S, int C, BnFinArgs a) {
+    int c; double s1, s2;
+    if (bn_slab_sum64_t<F64>(partials, S, C, blockIdx.x * 64, c, s1, s2)) bn_fin_bwd_channel(a, C, c, s1, s2);
 }
 
-extern "C" int nvae_bn_bwd_finalize(const float* partials, long rows, int C, const float* scale,
+static void launch_bn_bwd_finalize(int dtype, const float* partials, int S, long rows, int C, const float* scale,
+                                   const float* mean, const float* invstd, float* dgamma, float* dbeta, float* k0k1,
+                                   int frozen, hipStream_t s) {
+    BnFinArgs f{};
+    f.inv_n = 1.0f / (float)rows; f.scale = (float*)scale; f.mean = (float*)mean; f.invstd = (float*)invstd;
+    f.dgamma = dgamma; f.dbeta = dbeta; f.k0k1 = k0k1; f.frozen = frozen;
+    if (dtype == NVAE_F32) hipLaunchKernelGGL(k_bn_bwd_finalize<true>, cdiv(C, 64), 256, 0, s, (const void*)partials, S, C, f);
+    else hipLaunchKernelGGL(k_bn_bwd_finalize<false>, cdiv(C, 64), 256, 0, s, (const void*)partials, S, C, f);
+}
+
+extern "C" int nvae_bn_bwd_finalize(int dtype, const float* partials, long rows, int C, const float* scale,
                                     const float* mean, const float* invstd, float* dgamma, float* dbeta,
                                     float* k0k1, int frozen, void* stream) {
     NVAE_REQUIRE(rows > 0 && C > 0 && partials && k0k1, "bn_bwd_finalize: bad args");
-    const int S = nvae_reduce_splits(rows, C);
-    hipLaunchKernelGGL(k_bn_bwd_finalize, cdiv(C, 64), 256, 0, (hipStream_t)stream, partials, S,
-                       1.0f / (float)rows, C, scale, mean, invstd, dgamma, dbeta, k0k1, frozen);
+    launch_bn_bwd_finalize(dtype, partials, nvae_reduce_splits(rows, C), rows, C, scale, mean, invstd, dgamma, dbeta, k0k1,
+                           frozen, (hipStream_t)stream);
     NVAE_LAUNCH_CHECK("bn_bwd_finalize");
     return NVAE_OK;
 }
@@ -346,14 +330,13 @@ extern "C" int nvae_bn_bwd_reduce_fin(int dtype, const void* x, const void* dy, 
     return NVAE_OK;
 }
 
-// as nvae_bn_bwd_finalize for a slab with an explicit number of row splits (the conv-epilogue slab of
+// as nvae_bn_bwd_finalize for a slab with an explicit number of rows (the accumulated slab of
 // nvae_conv_gemm_bnbwd: S = nvae_conv_gemm_stats_rows)
-extern "C" int nvae_bn_bwd_finalize_s(const float* partials, int S, long rows, int C, const float* scale,
+extern "C" int nvae_bn_bwd_finalize_s(int dtype, const float* partials, int S, long rows, int C, const float* scale,
                                       const float* mean, const float* invstd, float* dgamma, float* dbeta,
                                       float* k0k1, int frozen, void* stream) {
     NVAE_REQUIRE(rows > 0 && C > 0 && S > 0 && partials && k0k1, "bn_bwd_finalize_s: bad args");
-    hipLaunchKernelGGL(k_bn_bwd_finalize, cdiv(C, 64), 256, 0, (hipStream_t)stream, partials, S,
-                       1.0f / (float)rows, C, scale, mean, invstd, dgamma, dbeta, k0k1, frozen);
+    launch_bn_bwd_finalize(dtype, partials, S, rows, C, scale, mean, invstd, dgamma, dbeta, k0k1, frozen, (hipStream_t)stream);
     NVAE_LAUNCH_CHECK("bn_bwd_finalize_s");
     return NVAE_OK;
 }
@@ -585,7 +568,9 @@ template <typename T>
 __global__ __launch_bounds__(RED_THREADS) void k_se_apply_stats(const T* __restrict__ x, const T* __restrict__ skip,
                                                                T* __restrict__ y, long rows, int C, int HW,
                                                                int rows_per_block, const float* __restrict__ gate,
-                                                               float ss, float bs, float* __restrict__ stats) {
+                                                               float ss, float bs, float* __restrict__ stats_) {
+    typedef typename StatT<T>::type ST;          // slab element type (bn_fin.h "statistics precision")
+    ST* __restrict__ stats = (ST*)stats_;
     const int TGS = C >= 64 ? 8 : (C > 16 ? (C > 32 ? 8 : 4) : (C > 8 ? 2 : 1));
     const int RL = RED_THREADS / TGS;
     const int tg = threadIdx.x % TGS, rl = threadIdx.x / TGS;
@@ -886,7 +871,9 @@ __global__ __launch_bounds__(RED_THREADS) void k_se_bwd_apply_bn(
     const T* __restrict__ dy, const float* __restrict__ gate, const float* __restrict__ dpool, T* __restrict__ dx,
     T* dskip, long rows, int C, int HW, int rows_per_block, float ss, float bs, int acc_dskip,
     const T* __restrict__ xb, const float* __restrict__ scale, const float* __restrict__ shift, int act,
-    float* __restrict__ partials) {
+    float* __restrict__ partials_) {
+    typedef typename StatT<T>::type ST;          // slab element type (bn_fin.h "statistics precision")
+    ST* __restrict__ partials = (ST*)partials_;
     const int TGS = C >= 64 ? 8 : (C > 16 ? (C > 32 ? 8 : 4) : (C > 8 ? 2 : 1));
     const int RL = RED_THREADS / TGS;
     const int tg = threadIdx.x % TGS, rl = threadIdx.x / TGS;
@@ -983,10 +970,10 @@ __global__ __launch_bounds__(RED_THREADS) void k_bn_apply_fin(
     const float* __restrict__ partials, int S, BnFinArgs a, int act) {
     __shared__ float s_sc[64], s_sh[64];
     {
-        int c; float s1, s2;
-        if (bn_slab_sum64(partials, S, C, blockIdx.x * 64, c, s1, s2)) {
-            const float m = s1 * a.inv_n;
-            const float var = fmaxf(s2 * a.inv_n - m * m, 0.f);
+        int c; double s1, s2;
+        if (bn_slab_sum64_t<sizeof(T) == 4>(partials, S, C, blockIdx.x * 64, c, s1, s2)) {
+            const double md = s1 * (double)a.inv_n;
+            const float m = (float)md, var = (float)fmax(s2 * (double)a.inv_n - md * md, 0.0);
             const float is = rsqrtf(var + a.eps);
             const float sc = a.gamma[c] * is, sh = a.beta[c] - m * sc;
             s_sc[c & 63] = sc; s_sh[c & 63] = sh;
@@ -1052,14 +1039,12 @@ __global__ __launch_bounds__(RED_THREADS) void k_bn_bwd_apply_fin(
     const float* __restrict__ partials, int S, BnFinArgs a, const float* __restrict__ shift, int act, int acc) {
     __shared__ float s_sc[64], s_sh[64], s_k0[64], s_k1[64];
     {
-        int c; float s1, s2;
-        if (bn_slab_sum64(partials, S, C, blockIdx.x * 64, c, s1, s2)) {
-            const float m = a.mean[c], is = a.invstd[c], sc = a.scale[c];
-            const float dg = is * (s2 - m * s1);
-            const float k1 = a.frozen ? 0.f : -sc * dg * is * a.inv_n;
-            const float k0 = a.frozen ? 0.f : -sc * s1 * a.inv_n - k1 * m;
-            s_sc[c & 63] = sc; s_sh[c & 63] = shift[c]; s_k0[c & 63] = k0; s_k1[c & 63] = k1;
-            if (blockIdx.y == 0) { a.dgamma[c] += dg; a.dbeta[c] += s1; }
+        int c; double s1, s2;
+        if (bn_slab_sum64_t<sizeof(T) == 4>(partials, S, C, blockIdx.x * 64, c, s1, s2)) {
+            float dg, k0, k1;
+            bn_bwd_coefs(a, c, s1, s2, dg, k0, k1);
+            s_sc[c & 63] = a.scale[c]; s_sh[c & 63] = shift[c]; s_k0[c & 63] = k0; s_k1[c & 63] = k1;
+            if (blockIdx.y == 0) { a.dgamma[c] += dg; a.dbeta[c] += (float)s1; }
         }
     }
     __syncthreads();

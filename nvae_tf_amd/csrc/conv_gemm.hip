@@ -103,21 +103,22 @@ __device__ __forceinline__ void conv_epilogue(f32x4 (&acc)[BM / WM / 16][BN / WN
     // ---- epilogue -------------------------------------------------------------------------
     // (a) optional BatchNorm statistics of the output tile, straight from the accumulators:
     //     per column sum and sum of squares over the tile's valid rows -> stats[bm][2][N]
+    typedef typename StatT<T>::type ST;                  // slab element type (bn_fin.h "statistics precision")
     if (stats) {
         __syncthreads();                                  // ring no longer read
-        float* red = lds_f;                         // [WM][BN][2]
+        ST* red = (ST*)lds_f;                       // [WM][BN][2]
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
             const int nl = wn * (BN / WN) + j * 16 + fr;
             const int n = bn * BN + nl;
             const float bv = (bias && n < N) ? bias[n] : 0.f;
-            float s1 = 0.f, s2 = 0.f;
+            ST s1 = 0, s2 = 0;
 #pragma unroll
             for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const long m = row_m(wm * (BM / WM) + i * 16 + fq * 4 + r);
-                    const float v = m >= 0 ? acc[i][j][r] + bv : 0.f;
+                    const ST v = m >= 0 ? (ST)(acc[i][j][r] + bv) : (ST)0;
                     s1 += v; s2 += v * v;
                 }
             s1 += __shfl_xor(s1, 16, 64); s1 += __shfl_xor(s1, 32, 64);
@@ -125,20 +126,21 @@ __device__ __forceinline__ void conv_epilogue(f32x4 (&acc)[BM / WM / 16][BN / WN
             if (fq == 0) { red[(wm * BN + nl) * 2] = s1; red[(wm * BN + nl) * 2 + 1] = s2; }
         }
         __syncthreads();
+        ST* slab = (ST*)stats;
         for (int nl = tid; nl < BN; nl += NT) {
             const int n = bn * BN + nl;
             if (n >= N) continue;
-            float s1 = 0.f, s2 = 0.f;
+            ST s1 = 0, s2 = 0;
 #pragma unroll
             for (int w = 0; w < WM; ++w) { s1 += red[(w * BN + nl) * 2]; s2 += red[(w * BN + nl) * 2 + 1]; }
             // M-tile bm adds into row bm % rows of the zeroed slab: at most 64 adders per address (measured on
             // MI355X, tools/mb_atomic.hip: <= 64 same-address float adders cost < 0.6 us and nobody waits for them;
             // 256 cost 7 us, 1024 26 us), and a consumer sums `rows` (1-8) rows instead of up to 512
             const int row = bm % be.rows;
-            atomicAdd(stats + ((long)row * 2) * N + n, s1);
-            atomicAdd(stats + ((long)row * 2 + 1) * N + n, s2);
+            atomicAdd(slab + ((long)row * 2) * N + n, s1);
+            atomicAdd(slab + ((long)row * 2 + 1) * N + n, s2);
         }
-        // forward statistics with an in-kernel finalize: take the arrival ticket now (only the slab stores are
+        // forward statistics with an in-kernel finalize: take the arrival ticket now (only the slab adds are
         // waited for; the ticket's round trip overlaps the output stores below), look at it when the kernel ends
         if (stats_counter) ticket = bn_arrive(stats_counter + bn);
     }
@@ -156,12 +158,13 @@ __device__ __forceinline__ void conv_epilogue(f32x4 (&acc)[BM / WM / 16][BN / WN
         const bool act_lane = rl < RPP;
         const int n0 = bn * BN + wn * WCOLS + c8 * 8;
         const bool nval = n0 < N;                          // N % 8 == 0 (checked by the host)
-        float sc[8], sh[8], s1[8], s2[8];
+        float sc[8], sh[8];
+        ST s1[8], s2[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             sc[e] = nval ? be.scale[n0 + e] : 0.f;
             sh[e] = nval ? be.shift[n0 + e] : 0.f;
-            s1[e] = 0.f; s2[e] = 0.f;
+            s1[e] = 0; s2[e] = 0;
         }
         const T* bx = (const T*)be.x;
         __syncthreads();
@@ -196,14 +199,14 @@ __device__ __forceinline__ void conv_epilogue(f32x4 (&acc)[BM / WM / 16][BN / WN
                     for (int e = 0; e < 8; ++e) {
                         float dpre = o[e];
                         if (be.act == ACT_SWISH) dpre *= dswishf_(xv[e] * sc[e] + sh[e]);
-                        s1[e] += dpre;
-                        s2[e] += dpre * xv[e];
+                        s1[e] += (ST)dpre;
+                        s2[e] += (ST)dpre * (ST)xv[e];
                     }
                 }
             __syncthreads();
         }
         // column sums of the tile: [WM * RPP row lanes][BN][2] through LDS, then one slab row per M-tile
-        float* red = lds_f;
+        ST* red = (ST*)lds_f;
         if (act_lane) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
@@ -215,18 +218,18 @@ __device__ __forceinline__ void conv_epilogue(f32x4 (&acc)[BM / WM / 16][BN / WN
         for (int nl = tid; nl < BN; nl += NT) {
             const int n = bn * BN + nl;
             if (n >= N) continue;
-            float a1 = 0.f, a2 = 0.f;
+            ST a1 = 0, a2 = 0;
             for (int w = 0; w < WM * RPP; ++w) { a1 += red[(w * BN + nl) * 2]; a2 += red[(w * BN + nl) * 2 + 1]; }
             const int row = bm % be.rows;
-            atomicAdd(be.partials + ((long)row * 2) * N + n, a1);
-            atomicAdd(be.partials + ((long)row * 2 + 1) * N + n, a2);
+            atomicAdd((ST*)be.partials + ((long)row * 2) * N + n, a1);
+            atomicAdd((ST*)be.partials + ((long)row * 2 + 1) * N + n, a2);
         }
         // With a counter the last M-tile of this column of tiles finalizes in place.  That makes every
         // workgroup wait for its own output stores and an atomic round trip before it frees its LDS
         // (measured: +4..8 us on kernels of 15-25 us), so the host normally passes no counter and runs
         // nvae_bn_bwd_finalize_s on the slab instead.
         if (be.fin.counter && bn_last_arriver(be.fin.counter + bn, be.m_tiles))
-            bn_fin_bwd(be.fin, be.partials, be.rows, N, bn * BN, (BN + 63) / 64);
+            bn_fin_bwd<sizeof(T) == 4>(be.fin, be.partials, be.rows, N, bn * BN, (BN + 63) / 64);
         return;
     }
     if (vec_epi) {
@@ -324,7 +327,9 @@ __global__ __launch_bounds__(WM* WN * 64) void k_conv_gemm2(
     static_assert(ACH >= 1 && BCH >= 1 && (NT / BKC) % 16 == 0, "tile/thread mismatch");
     static_assert(BKC == 8 || BKC == 16, "row width");
     static_assert(STAGES * STAGE * 16 >= WM * WN * 16 * (BN / WN + 4) * 4, "epilogue staging must fit in the ring");
-    static_assert(STAGES * STAGE * 16 >= WM * BN * 2 * 4, "stats scratch must fit in the ring");
+    static_assert(STAGES * STAGE * 16 >= WM * BN * 2 * 8, "stats scratch must fit in the ring");
+    static_assert(!BNBWD || STAGES * STAGE * 16 >= WM * ((64 / (BN / WN / 8)) < 16 ? (64 / (BN / WN / 8)) : 16) * BN * 2 * (int)sizeof(typename StatT<T>::type),
+                  "BN-backward scratch must fit in the ring");
     static_assert(STAGES >= 2 && STAGES <= 4, "ring depth");
     __shared__ uint4 lds[STAGES * STAGE];
     __shared__ __attribute__((aligned(16))) float pre_tab[PRE ? 2 * PRE_MAXC : 4];   // [scale | shift] of the prologue
@@ -408,7 +413,7 @@ __global__ __launch_bounds__(WM* WN * 64) void k_conv_gemm2(
     // prologue state: the (tap, channel) position of ring step t, which lags `issue` by STAGES-1 steps
     int p_kh = kh, p_kw = kw, p_ci = ci, p_kabs = kabs;
     if constexpr (PRE) {
-        for (int c = tid; c < g.Cin; c += NT) bn_coef(pre.bn, g.Cin, c, blockIdx.x == 0, pre_tab[c], pre_tab[PRE_MAXC + c]);
+        for (int c = tid; c < g.Cin; c += NT) bn_coef<sizeof(T) == 4>(pre.bn, g.Cin, c, blockIdx.x == 0, pre_tab[c], pre_tab[PRE_MAXC + c]);
         __syncthreads();
     }
     const int nk = (K + BKE - 1) / BKE;
@@ -479,7 +484,7 @@ __global__ __launch_bounds__(WM* WN * 64) void k_conv_gemm2(
     if constexpr (!BNBWD) {
         // the last M-tile of this column of tiles turns the statistics slab into the next BatchNorm's coefficients
         if (stats && sfin.counter && bn_was_last(sfin.counter + bn, ticket, be.m_tiles))
-            bn_fin_fwd(sfin, stats, be.rows, N, bn * BN, (BN + 63) / 64);
+            bn_fin_fwd<sizeof(T) == 4>(sfin, stats, be.rows, N, bn * BN, (BN + 63) / 64);
     }
 }
 
@@ -594,7 +599,7 @@ __global__ __launch_bounds__(WM * 128) void k_conv_halo(
         }
     };
     if constexpr (PRE) {
-        for (int c = tid; c < g.Cin; c += NT) bn_coef(pre.bn, g.Cin, c, blockIdx.x == 0, pre_tab[c], pre_tab[PRE_MAXC_HALO + c]);
+        for (int c = tid; c < g.Cin; c += NT) bn_coef<sizeof(T) == 4>(pre.bn, g.Cin, c, blockIdx.x == 0, pre_tab[c], pre_tab[PRE_MAXC_HALO + c]);
         __syncthreads();
     }
 #pragma unroll
@@ -718,7 +723,7 @@ __global__ __launch_bounds__(WM * 128) void k_conv_halo(
                                             sfin.counter, ticket);
     if constexpr (!BNBWD) {
         if (stats && sfin.counter && bn_was_last(sfin.counter + bn, ticket, be.m_tiles))
-            bn_fin_fwd(sfin, stats, be.rows, N, bn * BN, (BN + 63) / 64);
+            bn_fin_fwd<sizeof(T) == 4>(sfin, stats, be.rows, N, bn * BN, (BN + 63) / 64);
     }
 }
 

@@ -25,22 +25,23 @@
 #define SEF_MAX_H 128
 #define SEF_W_LDS 4096          // FC matrices of up to this many floats each are staged in LDS
 
-// cross-row-lane reduction of NQ per-thread 8-vectors: part is [NQ][RL][C] = NQ * 2048 floats
-template <int NQ>
-__device__ __forceinline__ void sef_scatter(float* part, const float (&a)[NQ][8], int rl, int tg, int C) {
+// cross-row-lane reduction of NQ per-thread 8-vectors: part is [NQ][RL][C] = NQ * 2048 elements
+template <int NQ, typename E>
+__device__ __forceinline__ void sef_scatter(E* part, const E (&a)[NQ][8], int rl, int tg, int C) {
 #pragma unroll
     for (int q = 0; q < NQ; ++q)
 #pragma unroll
         for (int j = 0; j < 8; ++j) part[q * 2048 + rl * C + tg * 8 + j] = a[q][j];
 }
-__device__ __forceinline__ float sef_gather(const float* part, int q, int c, int C, int RL) {
-    float v = 0.f;
+template <typename E>
+__device__ __forceinline__ E sef_gather(const E* part, int q, int c, int C, int RL) {
+    E v = 0;
     for (int k = 0; k < RL; ++k) v += part[q * 2048 + k * C + c];
     return v;
 }
 
 struct SefOut {                 // statistics of y for the BatchNorm that follows: rows of a ZEROED slab
-    float* stats; int rows;
+    void* stats; int rows;       // element type: StatT<T> (bn_fin.h "statistics precision")
 };
 
 // NCH > 0: HW == NCH * RL and the image's chunks stay in registers; NCH == 0: any HW, second pass re-reads
@@ -50,8 +51,10 @@ __global__ __launch_bounds__(256) void k_se_fused_fwd(
     int Hd, int imgs, const float* __restrict__ w1, const float* __restrict__ b1, const float* __restrict__ w2,
     const float* __restrict__ b2, float ss, float bs, float* __restrict__ pooled_sum,
     float* __restrict__ gate_out, float* __restrict__ hidden_out, SefOut so) {
+    typedef typename StatT<T>::type ST;
     __shared__ float p[SEF_MAX_C];
-    __shared__ float part[2 * 2048];
+    __shared__ ST part_s[2 * 2048];
+    float* part = (float*)part_s;                 // (the pooling pass uses the first 2048 floats of it)
     __shared__ float hd[SEF_MAX_H];
     __shared__ float s_w1[SEF_W_LDS], s_w2[SEF_W_LDS];
     __shared__ float s_sc[SEF_MAX_C], s_sh[SEF_MAX_C];
@@ -77,12 +80,12 @@ __global__ __launch_bounds__(256) void k_se_fused_fwd(
     if (has_bn)
         for (int c = threadIdx.x; c < C; c += 256) {
             float sc, sh;
-            bn_coef(bn, C, c, blockIdx.x == 0, sc, sh);
+            bn_coef<sizeof(T) == 4>(bn, C, c, blockIdx.x == 0, sc, sh);
             s_sc[c] = sc; s_sh[c] = sh;
         }
-    float st[2][8];
+    ST st[2][8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { st[0][j] = 0.f; st[1][j] = 0.f; }
+    for (int j = 0; j < 8; ++j) { st[0][j] = 0; st[1][j] = 0; }
     for (int im = 0; im < imgs; ++im, ++b) {
         if (b >= B) break;
         const T* xb = x + b * HW * C;
@@ -111,10 +114,10 @@ __global__ __launch_bounds__(256) void k_se_fused_fwd(
             }
         }
         __syncthreads();                       // previous image's readers of p / part / hd are done; tables are written
-        sef_scatter<1>(part, a, rl, tg, C);
+        sef_scatter<1, float>(part, a, rl, tg, C);
         __syncthreads();
         for (int c = threadIdx.x; c < C; c += 256) {
-            float v = sef_gather(part, 0, c, C, RL);
+            float v = sef_gather<float>(part, 0, c, C, RL);
             if (has_bn) v = s_sc[c] * v + (float)HW * s_sh[c];
             pooled_sum[b * C + c] = v;
             p[c] = v * inv_hw;
@@ -157,7 +160,7 @@ __global__ __launch_bounds__(256) void k_se_fused_fwd(
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     v[j] = ss * kv[i][j] + (xv[i][j] * sc[j] + sh[j]) * g8[j];
-                    st[0][j] += v[j]; st[1][j] += v[j] * v[j];
+                    st[0][j] += (ST)v[j]; st[1][j] += (ST)v[j] * (ST)v[j];
                 }
                 V8<T>::st(yb + (long)(rl + i * RL) * C + tg * 8, v);
             }
@@ -169,7 +172,7 @@ __global__ __launch_bounds__(256) void k_se_fused_fwd(
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     v[j] = ss * k[j] + (v[j] * sc[j] + sh[j]) * g8[j];
-                    st[0][j] += v[j]; st[1][j] += v[j] * v[j];
+                    st[0][j] += (ST)v[j]; st[1][j] += (ST)v[j] * (ST)v[j];
                 }
                 V8<T>::st(yb + (long)r * C + tg * 8, v);
             }
@@ -177,12 +180,13 @@ __global__ __launch_bounds__(256) void k_se_fused_fwd(
     }
     if (!so.stats) return;
     __syncthreads();
-    sef_scatter<2>(part, st, rl, tg, C);
+    sef_scatter<2, ST>(part_s, st, rl, tg, C);
     __syncthreads();
     const int row = blockIdx.x % so.rows;          // <= 64 adders per address (see conv_gemm.hip)
+    ST* slab = (ST*)so.stats;
     for (int c = threadIdx.x; c < C; c += 256) {
-        atomicAdd(so.stats + ((long)row * 2) * C + c, sef_gather(part, 0, c, C, RL));
-        atomicAdd(so.stats + ((long)row * 2 + 1) * C + c, sef_gather(part, 1, c, C, RL));
+        atomicAdd(slab + ((long)row * 2) * C + c, sef_gather<ST>(part_s, 0, c, C, RL));
+        atomicAdd(slab + ((long)row * 2 + 1) * C + c, sef_gather<ST>(part_s, 1, c, C, RL));
     }
 }
 
@@ -222,7 +226,7 @@ extern "C" int nvae_se_fused_fwd(int dtype, const void* x, const NvaeBnIn* bn_in
     BnFromSlab bn;
     if (int e = sef_bn("se_fused_fwd", bn_in, (long)B * HW, bn)) return e;
     const int imgs = sef_imgs(B), wgs = sef_wgs(B);
-    SefOut so{stats, cdiv(wgs, 64)};
+    SefOut so{(void*)stats, cdiv(wgs, 64)};
     const int RL = 256 / (C / 8);
     const int nch = (HW % RL == 0) ? HW / RL : 0;
 #define SEF_LAUNCH(N_)                                                                                              \
@@ -247,8 +251,10 @@ __global__ __launch_bounds__(256) void k_se_fused_bwd(
     const T* __restrict__ dy, const float* __restrict__ gate, const float* __restrict__ hidden, T* dx, T* dskip,
     int B, int HW, int C, int Hd, int imgs, const float* __restrict__ w1, const float* __restrict__ w2, float ss,
     float bs, int acc_dx, int acc_dskip, float* __restrict__ scratch, SefOut so) {
+    typedef typename StatT<T>::type ST;
     __shared__ float d2[SEF_MAX_C];
-    __shared__ float part[2 * 2048];
+    __shared__ ST part_s[2 * 2048];
+    float* part = (float*)part_s;
     __shared__ float d1[SEF_MAX_H];
     __shared__ float s_w1[SEF_W_LDS], s_w2[SEF_W_LDS];
     const int CG = C >> 3, RL = 256 / CG;
@@ -258,7 +264,7 @@ __global__ __launch_bounds__(256) void k_se_fused_bwd(
     const bool w_lds = C * Hd <= SEF_W_LDS;
     float* dpre2_out = scratch;
     float* dpre1_out = scratch + (long)B * C;
-    float* partials = so.stats;
+    ST* partials = (ST*)so.stats;
     constexpr int NR = NCH > 0 ? NCH : 1;
     float xv[NR][8], gv[NR][8];
     long b = (long)blockIdx.x * imgs;
@@ -274,9 +280,9 @@ __global__ __launch_bounds__(256) void k_se_fused_bwd(
     float sc[8], sh[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) { sc[j] = bn_scale ? bn_scale[tg * 8 + j] : 1.f; sh[j] = bn_scale ? bn_shift[tg * 8 + j] : 0.f; }
-    float st[2][8];
+    ST st[2][8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { st[0][j] = 0.f; st[1][j] = 0.f; }
+    for (int j = 0; j < 8; ++j) { st[0][j] = 0; st[1][j] = 0; }
     for (int im = 0; im < imgs; ++im, ++b) {
         if (b >= B) break;
         const T* xb = x + b * HW * C;
@@ -313,10 +319,10 @@ __global__ __launch_bounds__(256) void k_se_fused_bwd(
             }
         }
         __syncthreads();
-        sef_scatter<1>(part, a, rl, tg, C);
+        sef_scatter<1, float>(part, a, rl, tg, C);
         __syncthreads();
         for (int c = threadIdx.x; c < C; c += 256) {
-            const float r = sef_gather(part, 0, c, C, RL);
+            const float r = sef_gather<float>(part, 0, c, C, RL);
             const float g = gate[b * C + c];
             const float d = bs * r * g * (1.f - g);
             d2[c] = d;
@@ -359,7 +365,7 @@ __global__ __launch_bounds__(256) void k_se_fused_bwd(
                 if (partials) {
                     float dpre = d;
                     if (act == ACT_SWISH) dpre *= dswishf_(v[j] * sc[j] + sh[j]);
-                    st[0][j] += dpre; st[1][j] += dpre * v[j];
+                    st[0][j] += (ST)dpre; st[1][j] += (ST)dpre * (ST)v[j];
                 }
             }
             V8<T>::st(dxb + off, o);
@@ -380,12 +386,12 @@ __global__ __launch_bounds__(256) void k_se_fused_bwd(
     }
     if (!partials) return;
     __syncthreads();
-    sef_scatter<2>(part, st, rl, tg, C);
+    sef_scatter<2, ST>(part_s, st, rl, tg, C);
     __syncthreads();
     const int row = blockIdx.x % so.rows;
     for (int c = threadIdx.x; c < C; c += 256) {
-        atomicAdd(partials + ((long)row * 2) * C + c, sef_gather(part, 0, c, C, RL));
-        atomicAdd(partials + ((long)row * 2 + 1) * C + c, sef_gather(part, 1, c, C, RL));
+        atomicAdd(partials + ((long)row * 2) * C + c, sef_gather<ST>(part_s, 0, c, C, RL));
+        atomicAdd(partials + ((long)row * 2 + 1) * C + c, sef_gather<ST>(part_s, 1, c, C, RL));
     }
 }
 
@@ -402,7 +408,7 @@ extern "C" int nvae_se_fused_bwd(int dtype, const void* x, const float* bn_scale
     NVAE_REQUIRE(dskip || !acc_dskip, "se_fused_bwd: acc_dskip without dskip");
     NVAE_REQUIRE(!partials || (bn_scale && !acc_dx), "se_fused_bwd: BatchNorm sums need the coefficients and a final dx");
     const int imgs = sef_imgs(B), wgs = sef_wgs(B);
-    SefOut so{partials, cdiv(wgs, 64)};
+    SefOut so{(void*)partials, cdiv(wgs, 64)};
     const int RL = 256 / (C / 8);
     const int nch = (HW % RL == 0) ? HW / RL : 0;
 #define SEF_LAUNCH(N_)                                                                                                \

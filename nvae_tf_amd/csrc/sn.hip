@@ -2,9 +2,11 @@
 // encoder.py:92-98) as four multi-tensor passes over the flat f32 parameter buffer, plus the
 // preparation of the MFMA compute copies.  A workgroup owns 16 consecutive k rows of one weight
 // matrix W2d[K, Cout]; descs[i].blk_off maps workgroups to matrices (binary search).
-//   pass 1  t = W u            (row dots)          + |t|^2 per matrix
-//   pass 2  w2 = t^T W         (column sums, f32 atomics)
-//   pass 3  v W = w2 / |t|;  u' = l2n(v W);  sigma = (v W) . u'
+//   pass 1  t = W u            (row dots)
+//   pass 2  partial column sums of t^T W per 16-row workgroup -> colpart (plain stores)
+//   pass 3  |t|^2 and w2 = t^T W summed in a FIXED order;  v W = w2 / |t|;  u' = l2n(v W);  sigma = (v W) . u'
+//           (no atomics anywhere: sigma, and with it W <- W / sigma, is bit-reproducible, so data-parallel replicas
+//           that start identical stay identical without re-broadcasts)
 //   pass 4  W *= 1/sigma in place; write wF[Cout][K] and wD[Cin][taps flipped][Cout] in `dtype`
 // HBM traffic per step: 3 reads + 1 write of the masters and 2 writes of the copies.
 #include "common.h"
@@ -23,15 +25,13 @@ __device__ __forceinline__ int find_desc(const NvaeConvDesc* __restrict__ d, int
 }
 
 __global__ void k_sn_rowdot(const float* __restrict__ params, const NvaeConvDesc* __restrict__ descs,
-                            int n, const float* __restrict__ sn_state, float* __restrict__ t_out,
-                            float* nt2) {
+                            int n, const float* __restrict__ sn_state, float* __restrict__ t_out) {
     const int di = find_desc(descs, n, blockIdx.x);
     const NvaeConvDesc d = descs[di];
     const int k0 = (blockIdx.x - d.blk_off) * SN_ROWS;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const float* W = params + d.w_off;
     const float* u = sn_state + d.u_off;
-    float sq = 0.f;
     // a wave owns rows wave, wave+4, wave+8, wave+12 and walks them TOGETHER: four independent
     // accumulators per lane, u read once per column group, 16-B loads when Cout allows (it always does
     // on this path: Cout % 8 == 0 except the 1-channel logit head)
@@ -63,16 +63,12 @@ __global__ void k_sn_rowdot(const float* __restrict__ params, const NvaeConvDesc
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const float v = wave_sum(a[q]);
-        if (lane == 0 && rv[q]) {
-            t_out[d.t_off + k0 + wave + 4 * q] = v;
-            sq += v * v;
-        }
+        if (lane == 0 && rv[q]) t_out[d.t_off + k0 + wave + 4 * q] = v;
     }
-    if (lane == 0 && sq != 0.f) atomicAdd(nt2 + d.idx, sq);
 }
 
 __global__ void k_sn_colsum(const float* __restrict__ params, const NvaeConvDesc* __restrict__ descs,
-                            int n, const float* __restrict__ t_in, float* w2) {
+                            int n, const float* __restrict__ t_in, float* __restrict__ colpart) {
     const int di = find_desc(descs, n, blockIdx.x);
     const NvaeConvDesc d = descs[di];
     const int k0 = (blockIdx.x - d.blk_off) * SN_ROWS;
@@ -85,36 +81,50 @@ __global__ void k_sn_colsum(const float* __restrict__ params, const NvaeConvDesc
     for (int c = threadIdx.x; c < d.Cout; c += 256) {
         float a = 0.f;
         for (int r = 0; r < rows; ++r) a += tt[r] * W[(long)r * d.Cout + c];
-        atomicAdd(w2 + d.u_off + c, a);
+        colpart[d.p_off + (long)(blockIdx.x - d.blk_off) * d.Cout + c] = a;
     }
 }
 
 __global__ void k_sn_finish(const NvaeConvDesc* __restrict__ descs, float* __restrict__ sn_state,
-                            const float* __restrict__ nt2, const float* __restrict__ w2,
-                            float* __restrict__ inv_sigma) {
+                            const float* __restrict__ t_in, const float* __restrict__ colpart,
+                            float* __restrict__ w2, float* __restrict__ inv_sigma) {
     __shared__ float sm[4];
     const NvaeConvDesc d = descs[blockIdx.x];
-    const float inv_nt = rsqrtf(fmaxf(nt2[d.idx], SN_L2_EPS));
+    const int nblk = (d.K + SN_ROWS - 1) / SN_ROWS;
+    // |t|^2 and the column sums, each in a fixed order (thread-strided partial sums, then block_sum256's tree)
     float a = 0.f;
+    for (int k = threadIdx.x; k < d.K; k += 256) { const float v = t_in[d.t_off + k]; a += v * v; }
+    const float nt2 = block_sum256(a, sm);
+    const float inv_nt = rsqrtf(fmaxf(nt2, SN_L2_EPS));
+    a = 0.f;
     for (int c = threadIdx.x; c < d.Cout; c += 256) {
-        float v = w2[d.u_off + c] * inv_nt;
+        const float* p = colpart + d.p_off + c;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int b = 0;
+        for (; b + 4 <= nblk; b += 4) {
+            s0 += p[(long)b * d.Cout]; s1 += p[(long)(b + 1) * d.Cout];
+            s2 += p[(long)(b + 2) * d.Cout]; s3 += p[(long)(b + 3) * d.Cout];
+        }
+        for (; b < nblk; ++b) s0 += p[(long)b * d.Cout];
+        const float v = ((s0 + s1) + (s2 + s3)) * inv_nt;
+        w2[d.u_off + c] = v;                          // read back below by the thread that wrote it
         a += v * v;
     }
     a = block_sum256(a, sm);
     const float inv_nu = rsqrtf(fmaxf(a, SN_L2_EPS));
-    for (int c = threadIdx.x; c < d.Cout; c += 256) sn_state[d.u_off + c] = w2[d.u_off + c] * inv_nt * inv_nu;
+    for (int c = threadIdx.x; c < d.Cout; c += 256) sn_state[d.u_off + c] = w2[d.u_off + c] * inv_nu;
     if (threadIdx.x == 0) inv_sigma[d.idx] = 1.0f / (a * inv_nu);   // sigma = sum (vW)^2 * inv_nu
 }
 
 extern "C" int nvae_sn_power_iter(float* params, const NvaeConvDesc* descs, int n, int total_blocks,
-                                  float* sn_state, float* sn_scratch_t, float* nt2, float* w2,
+                                  float* sn_state, float* sn_scratch_t, float* colpart, float* w2,
                                   float* inv_sigma, void* stream) {
-    NVAE_REQUIRE(n > 0 && total_blocks > 0 && params && descs && sn_state && sn_scratch_t && nt2 && w2 && inv_sigma,
+    NVAE_REQUIRE(n > 0 && total_blocks > 0 && params && descs && sn_state && sn_scratch_t && colpart && w2 && inv_sigma,
                  "sn_power_iter: bad args");
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_sn_rowdot, total_blocks, 256, 0, s, params, descs, n, sn_state, sn_scratch_t, nt2);
-    hipLaunchKernelGGL(k_sn_colsum, total_blocks, 256, 0, s, params, descs, n, sn_scratch_t, w2);
-    hipLaunchKernelGGL(k_sn_finish, n, 256, 0, s, descs, sn_state, nt2, w2, inv_sigma);
+    hipLaunchKernelGGL(k_sn_rowdot, total_blocks, 256, 0, s, params, descs, n, sn_state, sn_scratch_t);
+    hipLaunchKernelGGL(k_sn_colsum, total_blocks, 256, 0, s, params, descs, n, sn_scratch_t, colpart);
+    hipLaunchKernelGGL(k_sn_finish, n, 256, 0, s, descs, sn_state, sn_scratch_t, colpart, w2, inv_sigma);
     NVAE_LAUNCH_CHECK("sn_power_iter");
     return NVAE_OK;
 }

@@ -45,21 +45,28 @@ class Encoder:
     def __init__(self, ps, n_encoder_channels, n_decoder_channels, n_latent_per_group, res_cells_per_group,
                  n_latent_scales, n_groups_per_scale: List[int], mult, scale_factor, input_shape):
         self.groups = []
+        # flat-parameter offset at which each entry of `groups` starts, and (filled in by __call__) the tape index
+        # at which its forward work starts: cut points for the segmented, all-reduce-overlapped backward pass
+        self.group_param_off: List[int] = []
+        self.group_tape_idx: List[int] = []
         gi = ti = 0
         shape = list(input_shape)
         for scale in range(n_latent_scales):
             n_groups = n_groups_per_scale[scale]
             for group_idx in range(n_groups):
                 c = n_encoder_channels * mult
+                self.group_param_off.append(ps._p_cursor)
                 self.groups.append([EncodingResidualCell(ps, f"enc.g{gi}.c{i}", c)
                                     for i in range(res_cells_per_group)])
                 gi += 1
                 if not (scale == n_latent_scales - 1 and group_idx == n_groups - 1):
+                    self.group_param_off.append(ps._p_cursor)
                     self.groups.append(EncoderDecoderCombiner(ps, f"enc.comb{ti}",
                                                               n_decoder_channels * mult, c))
                     ti += 1
             if scale < n_latent_scales - 1:
                 c = n_encoder_channels * mult
+                self.group_param_off.append(ps._p_cursor)
                 self.groups.append(Rescaler(ps, f"enc.down{scale}", c, c * scale_factor, scale_factor,
                                             RescaleType.DOWN, in_bn_loss=True))
                 mult *= scale_factor
@@ -70,7 +77,9 @@ class Encoder:
 
     def __call__(self, ctx: Ctx, x: Var):
         enc_dec_combiners = []
+        self.group_tape_idx = []
         for group in self.groups:
+            self.group_tape_idx.append(len(ctx.tape))
             if isinstance(group, EncoderDecoderCombiner):
                 enc_dec_combiners.append(partial(group, ctx, x))   # evaluated later by the decoder
             elif isinstance(group, list):

@@ -90,10 +90,11 @@ class NVAE:
         self.steps = 0          # updated for each training step (models.py:86-87)
         self.opt_iterations = 0
         self.reducer = None     # parallel.GradReducer when data-parallel
-        # DP: backward runs in three tape segments (postprocess | decoder | encoder + preprocess); the
-        # parameters of a finished segment are all-reduced while the next one computes
+        # DP: backward runs in tape segments (postprocess | decoder | encoder top | encoder middle | encoder bottom +
+        # preprocess); the parameters of a finished segment are all-reduced while the next one computes
         self.overlap_allreduce = True
         self._tape_marks = (0, 0)
+        self._segments = []          # [(tape_lo, tape_hi, grad_lo, grad_hi)] in backward order, set by _forward
         dev = self.device
         self.hyper = torch.zeros(L.HY_SIZE, dtype=torch.float32, device=dev)
         self.results = torch.zeros(L.RES_SIZE, dtype=torch.float32, device=dev)
@@ -177,7 +178,36 @@ class NVAE:
                          1.0 / B, nll=nll, log_p=buf["log_p"], log_q=buf["log_q"],
                          mu_sigma_list=mu_sigma_list)
         self._tape_marks = (enc_mark, len(ctx.tape))
-        return self.postprocess(ctx, s)
+        dec_mark = len(ctx.tape)
+        logits = self.postprocess(ctx, s)
+        if ctx.record:
+            self._segments = self._make_segments(enc_mark, dec_mark, len(ctx.tape))
+        return logits
+
+    def _make_segments(self, enc_mark: int, dec_mark: int, end: int):
+        """Backward segments (tape range, flat gradient range that is FINAL once the range has run), in backward
+        order.  Parameters live in construction order (pre | enc | dec | post) and the tape runs in reverse, so
+        after a tape suffix has run the gradients of everything constructed at or after its first layer are final
+        (the encoder's combiner convs run inside the decoder's tape: final even earlier).  The encoder + preprocess
+        range (45 % of the parameters) is cut twice at encoder group boundaries, so that the all-reduce left
+        exposed after the last kernel covers about a quarter of it (~28 MB at C2) instead of 112 MB."""
+        m = self.param_marks
+        segs = [(dec_mark, end, m[3], m[4]), (enc_mark, dec_mark, m[2], m[3])]
+        enc = self.encoder
+        offs, idxs = enc.group_param_off, enc.group_tape_idx
+        total = m[2] - m[0]
+        cuts = []
+        for frac in (0.6, 0.25):
+            cand = [i for i in range(1, len(offs)) if offs[i] - m[0] <= frac * total and idxs[i] > 0]
+            if cand and (not cuts or cand[-1] < cuts[-1]):
+                cuts.append(cand[-1])
+        hi_t, hi_p = enc_mark, m[2]
+        for ci in cuts:                       # descending group index = backward order
+            if idxs[ci] < hi_t and offs[ci] < hi_p:
+                segs.append((idxs[ci], hi_t, offs[ci], hi_p))
+                hi_t, hi_p = idxs[ci], offs[ci]
+        segs.append((0, hi_t, m[0], hi_p))
+        return segs
 
     def __call__(self, inputs, nll=False, eps_list=None, training=False):
         """NVAE.call, models.py:89-98 -> (reconstruction logits, z_params, log_p, log_q)."""
@@ -292,10 +322,13 @@ class NVAE:
         self._logits = logits
         return ctx
 
+    def n_segments(self) -> int:
+        return len(self._segments)
+
     def _seg_backward(self, ctx: Ctx, B: int, part: Optional[int] = None):
-        """Loss + backward.  part=None: everything.  part 0 / 1 / 2: the postprocess / decoder /
-        encoder + preprocess segment of the tape (run in that order); after part k the gradients of
-        flat-buffer range `self.grad_range(k)` are final."""
+        """Loss + backward.  part=None: everything.  part k: segment k of `self._segments` (postprocess, decoder,
+        then the encoder + preprocess pieces; run in that order); after part k the gradients of flat-buffer
+        range `self.grad_range(k)` are final."""
         ps = self.ps
         if part in (None, 0):
             buf = self._buffers(B)
@@ -306,21 +339,15 @@ class NVAE:
             if nb:      # subgradient of the BN regulariser: depends on the parameters only, so it goes first
                 L.call("nvae_bn_absmax_bwd", L.ptr(ps.params), L.ptr(ps.grads), L.ptr(ps.bn_table),
                        L.ptr(ps.bn_argmax), nb, float(self.sr_lambda))
-        enc_mark, dec_mark = self._tape_marks
         if part is None:
             ctx.backward()
-        elif part == 0:
-            ctx.backward(dec_mark, None)
-        elif part == 1:
-            ctx.backward(enc_mark, dec_mark)
         else:
-            ctx.backward(0, enc_mark)
+            lo, hi = self._segments[part][:2]
+            ctx.backward(lo, hi)
 
     def grad_range(self, part: int):
-        """Flat gradient range completed by backward segment `part` (0: postprocess, 1: decoder,
-        2: preprocess + encoder; the encoder range also holds the combiner convs the decoder runs)."""
-        m = self.param_marks
-        return [(m[3], m[4]), (m[2], m[3]), (m[0], m[2])][part]
+        """Flat gradient range completed by backward segment `part` (see _make_segments)."""
+        return self._segments[part][2:]
 
     def sync_replicas(self):
         """Re-align the replicas on rank 0's parameters and state.  The averaged gradients are
@@ -351,7 +378,7 @@ class NVAE:
             self.reducer.allreduce_mean_(self.am)
         if self._dp_segments():
             works = []
-            for part in range(3):
+            for part in range(self.n_segments()):
                 self._seg_backward(ctx, B, part)
                 self.reducer.start_allreduce_(self.ps.grads, *self.grad_range(part), works)
             self.reducer.finish_allreduce_(works)
@@ -376,8 +403,8 @@ class NVAE:
         """Capture the training step into hipGraphs for a fixed batch shape.  The step is
         [graph: SN + forward + loss stats] -> (all-reduce of the [G] KL statistic when DP)
         -> [graph: loss + backward] -> (gradient all-reduce when DP) -> [graph: Adamax].
-        With a reducer and overlap_allreduce the backward graph is three graphs (postprocess | decoder
-        | encoder + preprocess) and each segment's gradient range is all-reduced while the next replays.
+        With a reducer and overlap_allreduce the backward graph is one graph per segment (postprocess | decoder
+        | three encoder + preprocess pieces) and each segment's gradient range is all-reduced while the next replays.
         Host-side scalars (lr, beta) reach the kernels through the `hyper` device buffer, noise is
         drawn in-graph from a device counter, so replays are exact continuations of training.
 
@@ -413,7 +440,7 @@ class NVAE:
             ctx = self._seg_forward(self._static_x, None)
         if self._dp_segments():
             g2 = []
-            for part in range(3):
+            for part in range(self.n_segments()):
                 g2.append(torch.cuda.CUDAGraph())
                 with torch.cuda.graph(g2[-1], **kw):
                     self._seg_backward(ctx, B, part)

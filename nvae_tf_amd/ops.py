@@ -110,6 +110,21 @@ class Ctx:
         self.zero_cursor += n_al
         return out
 
+    def slab_dtype(self) -> torch.dtype:
+        """Element type of every BatchNorm statistics slab: f64 on the f32 activation path (include/nvae_hip.h
+        "STATISTICS SLABS")."""
+        return torch.float64 if self.dtype == torch.float32 else torch.float32
+
+    def zero_slab(self, rows: int, C_: int) -> torch.Tensor:
+        """A zeroed [rows, 2, C] statistics slab (producers add into it with atomics) from the per-step pool."""
+        n = rows * 2 * C_
+        if self.dtype == torch.float32:
+            return self.zeros_f32(2 * n).view(torch.float64).view(rows, 2, C_)
+        return self.zeros_f32(n).view(rows, 2, C_)
+
+    def empty_slab(self, rows: int, C_: int) -> torch.Tensor:
+        return self.empty((rows, 2, C_), self.slab_dtype())
+
     def counters(self) -> int:
         """Arrival counters of the fused BatchNorm finalizes (csrc/bn_fin.h): zero at rest, shared by
         all launches of the main stream (they are serialised there)."""
@@ -319,7 +334,7 @@ def conv2d(ctx: Ctx, x: Var, conv, *, stride: int = 1, up: int = 1, pad: Optiona
         if want_stats and ctx.training and not accumulate and out_coff == 0 and Cy == cout:
             # the conv's epilogue emits the BatchNorm statistics of its output (consumed by bn_act)
             S = lib.nvae_conv_gemm_stats_rows(ctx.dt, C.byref(g))
-            slab = ctx.zeros_f32(S * 2 * cout).view(S, 2, cout)      # accumulated into with atomics
+            slab = ctx.zero_slab(S, cout)      # accumulated into with atomics
             out.stats = (slab, S)
             if want_fin(ctx, stats_bn):
                 coef = ctx.empty((4, cout), torch.float32)
@@ -386,7 +401,7 @@ def conv2d(ctx: Ctx, x: Var, conv, *, stride: int = 1, up: int = 1, pad: Optiona
                     # the epilogue of the data-gradient kernel (the BN closure then only applies)
                     wD = ptr(ps.wcopies) + conv.wd_off * ps.wcopies.element_size()
                     mt = L.load().nvae_conv_gemm_stats_rows(ctx.dt, C.byref(gd))
-                    src["partials"] = ctx.zeros_f32(mt * 2 * Cx).view(mt, 2, Cx)
+                    src["partials"] = ctx.zero_slab(mt, Cx)
                     src["k0k1"] = ctx.empty((2, Cx), torch.float32)
                     src["mtiles"] = mt
                     f = L.BnBwdFuse(ptr(src["x"]), Cx, src["act"], src["frozen"], src["scale"], src["shift"],
@@ -420,7 +435,7 @@ def dwconv5(ctx: Ctx, x: Var, dw, want_stats: bool = False) -> Var:
     y = Var(ctx.empty(x.shape))
     rows = L.load().nvae_dwconv5_stats_rows(ctx.dt, B, H, W, Cc) if (want_stats and ctx.training) else 0
     if rows > 0:
-        slab = ctx.zeros_f32(rows * 2 * Cc).view(rows, 2, Cc)       # accumulated into with atomics
+        slab = ctx.zero_slab(rows, Cc)       # accumulated into with atomics
         call("nvae_dwconv5_stats", ctx.dt, ptr(xt), ptr(ps.view(dw.w)), ptr(ps.view(dw.b)), ptr(y.t), B, H, W, Cc,
              ptr(slab))
         y.stats = (slab, rows)
@@ -482,7 +497,7 @@ class LazyBN:
         if not self.ready:
             slab, Sx = self.x.stats
             B, H, W, Cc = self.x.shape
-            call("nvae_bn_finalize_s", ptr(slab), Sx, B * H * W, Cc, *self._bn_args(), BN_MOMENTUM, BN_EPS, self.scale,
+            call("nvae_bn_finalize_s", self.ctx.dt, ptr(slab), Sx, B * H * W, Cc, *self._bn_args(), BN_MOMENTUM, BN_EPS, self.scale,
                  self.shift, self.mean, self.invstd)
             self.ready = True
         return self.scale, self.shift
@@ -534,7 +549,7 @@ def bn_act(ctx: Ctx, x: Var, bn, act: int = L.ACT_NONE, lazy: bool = True) -> Va
         if ctx.training and x.stats is not None:
             ready = False                               # slab only: finalized by whoever needs the table first
         elif ctx.training:
-            partials = ctx.empty((S, 2, Cc), _stats_slab_dtype(ctx))
+            partials = ctx.empty_slab(S, Cc)
             if FUSED_FIN:
                 call("nvae_bn_stats_fin", ctx.dt, ptr(x.t), rows, Cc, ptr(partials), ctx.counters(), gamma, beta, rm,
                      rv, BN_MOMENTUM, BN_EPS, scale, shift, mean, invstd)
@@ -569,21 +584,21 @@ def bn_act(ctx: Ctx, x: Var, bn, act: int = L.ACT_NONE, lazy: bool = True) -> Va
                      info["mtiles"], scale, shift, mean, invstd, dgamma, dbeta, act, frozen, acc)
                 return
             if info["fused"]:
-                call("nvae_bn_bwd_finalize_s", ptr(info["partials"]), info["mtiles"], rows, Cc, scale, mean, invstd,
+                call("nvae_bn_bwd_finalize_s", ctx.dt, ptr(info["partials"]), info["mtiles"], rows, Cc, scale, mean, invstd,
                      dgamma, dbeta, ptr(info["k0k1"]), frozen)
                 if x.needs_grad:
                     g, acc = ctx.grad_of(x)
                     call("nvae_bn_bwd_apply", ctx.dt, ptr(xt), ptr(y.g), ptr(g), rows, Cc, scale, shift,
                          ptr(info["k0k1"]), act, acc)
                 return
-            part = ctx.empty((S, 2, Cc), torch.float32)
+            part = ctx.empty_slab(S, Cc)
             k0k1 = ctx.empty((2, Cc), torch.float32)
             if FUSED_FIN:
                 call("nvae_bn_bwd_reduce_fin", ctx.dt, ptr(xt), ptr(y.g), rows, Cc, scale, shift, mean, invstd,
                      act, ptr(part), ctx.counters(), dgamma, dbeta, ptr(k0k1), frozen)
             else:
                 call("nvae_bn_bwd_reduce", ctx.dt, ptr(xt), ptr(y.g), rows, Cc, scale, shift, act, ptr(part))
-                call("nvae_bn_bwd_finalize", ptr(part), rows, Cc, scale, mean, invstd, dgamma, dbeta, ptr(k0k1),
+                call("nvae_bn_bwd_finalize", ctx.dt, ptr(part), rows, Cc, scale, mean, invstd, dgamma, dbeta, ptr(k0k1),
                      frozen)
             if x.needs_grad:
                 g, acc = ctx.grad_of(x)
@@ -627,7 +642,7 @@ def se_residual(ctx: Ctx, x: Var, se, skip: Var, skip_scale: float, branch_scale
         slab = None
         if ctx.training and SE_STATS:
             S = L.load().nvae_se_fused_rows(B)
-            slab = ctx.zeros_f32(S * 2 * Cc).view(S, 2, Cc)
+            slab = ctx.zero_slab(S, Cc)
             y.stats = (slab, S)
         call("nvae_se_fused_fwd", ctx.dt, ptr(xin_t), bn_in, ptr(skip.t), ptr(y.t), B, HW, Cc, Hd,
              w1, b1, w2, b2, skip_scale, branch_scale, ptr(pooled), ptr(gate), ptr(hidden), ptr(slab))
@@ -640,7 +655,7 @@ def se_residual(ctx: Ctx, x: Var, se, skip: Var, skip_scale: float, branch_scale
         if ctx.training and SE_STATS:
             # the consumer is almost always the next cell's BatchNorm: emit its statistics slab here
             S = L.load().nvae_reduce_splits(B * HW, Cc)
-            slab = ctx.empty((S, 2, Cc), torch.float32)
+            slab = ctx.empty_slab(S, Cc)
             call("nvae_se_apply_stats", ctx.dt, ptr(x.t), ptr(skip.t), ptr(y.t), B, HW, Cc, ptr(gate), skip_scale,
                  branch_scale, ptr(slab))
             y.stats = (slab, S)
@@ -664,7 +679,7 @@ def se_residual(ctx: Ctx, x: Var, se, skip: Var, skip_scale: float, branch_scale
                 if fuse:
                     # x = act(BN(xb)) with this SE as its only consumer: dx is final, reduce the BN backward sums here
                     S = L.load().nvae_se_fused_rows(B)
-                    src["partials"] = ctx.zeros_f32(S * 2 * Cc).view(S, 2, Cc)
+                    src["partials"] = ctx.zero_slab(S, Cc)
                     src["k0k1"] = ctx.empty((2, Cc), torch.float32)
                     src["mtiles"] = S
                     src["fused"] = True
@@ -704,7 +719,7 @@ def se_residual(ctx: Ctx, x: Var, se, skip: Var, skip_scale: float, branch_scale
             if fuse:
                 # x = act(BN(xb)) with this SE as its only consumer: dx is final, reduce the BN backward sums here
                 S = L.load().nvae_reduce_splits(B * HW, Cc)
-                src["partials"] = ctx.empty((S, 2, Cc), torch.float32)
+                src["partials"] = ctx.empty_slab(S, Cc)
                 src["k0k1"] = ctx.empty((2, Cc), torch.float32)
                 src["mtiles"] = S
                 call("nvae_se_bwd_apply_bn", ctx.dt, ptr(y.g), ptr(gate), ptr(dpool), ptr(gx), gs_ptr, B, HW, Cc,

@@ -157,12 +157,10 @@ class ParamStore:
         self.adam_m = torch.zeros(P, dtype=torch.float32, device=device)
         self.adam_u = torch.zeros(P, dtype=torch.float32, device=device)
         self.zero_pool = torch.zeros(zero_pool_floats, dtype=torch.float32, device=device)
-        # head of the pool is reserved for the spectral-norm scratch: nt2[n_convs] | w2[state layout]
-        self.zero_reserved = (len(self.convs) + 7) // 8 * 8 + (S + 7) // 8 * 8
-        assert self.zero_reserved < zero_pool_floats
+        self.zero_reserved = 0
         # ---- compute copies + descriptors for spectral norm / weight prep
         ve = 8 if dtype == torch.bfloat16 else 4
-        cursor = t_cursor = blk = 0
+        cursor = t_cursor = blk = p_cursor = 0
         descs = (L.ConvDesc * len(self.convs))()
         for i, c in enumerate(self.convs):
             K = c.k * c.k * c.cin
@@ -179,9 +177,10 @@ class ParamStore:
             d.w_off, d.wf_off, d.wd_off = c.w.off, c.wf_off, c.wd_off
             d.u_off = c.u.off if c.u is not None else 0
             d.t_off, d.K, d.Cout, d.Cin, d.taps = t_cursor, K, c.cout, c.cin, c.k * c.k
-            d.wf_ld, d.wd_ld, d.idx, d.blk_off = c.wf_ld, c.wd_ld, i, blk
+            d.wf_ld, d.wd_ld, d.idx, d.blk_off, d.p_off = c.wf_ld, c.wd_ld, i, blk, p_cursor
             t_cursor += (K + 7) // 8 * 8
             blk += (K + 15) // 16
+            p_cursor += (K + 15) // 16 * c.cout
         self.n_convs = len(self.convs)
         self.sn_blocks = blk
         self.wcopies = torch.zeros(max(cursor, 16), dtype=dtype, device=device)
@@ -189,6 +188,9 @@ class ParamStore:
         self.descs = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(device)
         self.sn_t = torch.zeros(max(t_cursor, 8), dtype=torch.float32, device=device)
         self.sn_inv_sigma = torch.ones(max(self.n_convs, 1), dtype=torch.float32, device=device)
+        # spectral-norm scratch: per-16-row partial column sums, and w2 laid out like `state` (no zeroing needed)
+        self.sn_colpart = torch.empty(max(p_cursor, 8), dtype=torch.float32, device=device)
+        self.sn_w2 = torch.empty(S, dtype=torch.float32, device=device)
         # BN-loss table
         tab = [[b.gamma.off, b.c] for b in self.bn_loss_layers] or [[0, 0]]
         self.bn_table = torch.tensor(tab, dtype=torch.int32, device=device)
@@ -252,10 +254,9 @@ class ParamStore:
         dt = L.dtype_code(self.dtype)
         inv = None
         if spectral_norm:
-            nt2 = self.zero_pool[:self.n_convs]
-            w2 = self.zero_pool[(self.n_convs + 7) // 8 * 8:self.zero_reserved]
             L.call("nvae_sn_power_iter", L.ptr(self.params), L.ptr(self.descs), self.n_convs, self.sn_blocks,
-                   L.ptr(self.state), L.ptr(self.sn_t), L.ptr(nt2), L.ptr(w2), L.ptr(self.sn_inv_sigma))
+                   L.ptr(self.state), L.ptr(self.sn_t), L.ptr(self.sn_colpart), L.ptr(self.sn_w2),
+                   L.ptr(self.sn_inv_sigma))
             inv = L.ptr(self.sn_inv_sigma)
         L.call("nvae_weight_prep", dt, L.ptr(self.params), L.ptr(self.descs), self.n_convs, self.sn_blocks,
                inv, L.ptr(self.wcopies))

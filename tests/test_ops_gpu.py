@@ -260,7 +260,7 @@ def test_bn_fused_finalize_matches_two_launch(lib, dev, shape):
             call("nvae_bn_finalize", 1, ptr(part), rows, Cc, ptr(gamma), ptr(beta), ptr(rm), ptr(rv), 0.05, 1e-5, sc,
                  sh, mean, istd)
             call("nvae_bn_bwd_reduce", 1, ptr(x), ptr(dy), rows, Cc, sc, sh, 1, ptr(part))
-            call("nvae_bn_bwd_finalize", ptr(part), rows, Cc, sc, mean, istd, ptr(dg), ptr(db), ptr(k), 0)
+            call("nvae_bn_bwd_finalize", 1, ptr(part), rows, Cc, sc, mean, istd, ptr(dg), ptr(db), ptr(k), 0)
         torch.cuda.synchronize()
         return [t.clone() for t in (coef, rm, rv, dg, db, k)]
 

@@ -21,6 +21,14 @@ for r in rows:
             break
 for n, (c, t) in fam.items():
     print(f"  family {n:36s} {c/steps:7.1f} launches/step {t/1e6/steps:7.3f} ms/step avg {t/1e3/max(c,1):7.1f} us")
+js = [a for a in sys.argv if a.startswith("--json=")]
+if js:
+    import json
+    with open(js[0].split("=", 1)[1], "w") as fh:
+        json.dump({"source": "rocprofv3 --kernel-trace --stats of bench.py", "steps_in_run": steps,
+                   "kernel_time_ms_per_step": round(tot / 1e6 / steps, 3), "launches_per_step": round(calls / steps, 1),
+                   "families": {n: {"launches_per_step": round(c / steps, 1), "ms_per_step": round(t / 1e6 / steps, 3),
+                                    "avg_us": round(t / 1e3 / max(c, 1), 1)} for n, (c, t) in fam.items()}}, fh, indent=1)
 for r in rows[:40]:
     print(f'{r["Name"][:70]:70s} calls={int(r["Calls"]):6d} total={float(r["TotalDurationNs"])/1e6/steps:8.3f} ms/step avg={float(r["AverageNs"])/1e3:8.1f} us {float(r["Percentage"]):5.1f}%')
 if "--grid" in sys.argv:
