@@ -343,7 +343,7 @@ class NVAE:
             ctx.backward()
         else:
             lo, hi = self._segments[part][:2]
-            ctx.backward(lo, hi)
+            ctx.backward(lo, hi if part else None)      # (the loss ops appended after the forward pass belong to segment 0)
 
     def grad_range(self, part: int):
         """Flat gradient range completed by backward segment `part` (see _make_segments)."""
