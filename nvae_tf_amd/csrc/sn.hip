@@ -24,46 +24,51 @@ __device__ __forceinline__ int find_desc(const NvaeConvDesc* __restrict__ d, int
     return lo;
 }
 
+// SN_BPW consecutive 16-row blocks per workgroup: one block is 1-24 KB of weights, too little for a workgroup of
+// its own (15 855 workgroups of ~1 us each ran at 0.9 TB/s)
+#define SN_BPW 8
 __global__ void k_sn_rowdot(const float* __restrict__ params, const NvaeConvDesc* __restrict__ descs,
-                            int n, const float* __restrict__ sn_state, float* __restrict__ t_out) {
-    const int di = find_desc(descs, n, blockIdx.x);
-    const NvaeConvDesc d = descs[di];
-    const int k0 = (blockIdx.x - d.blk_off) * SN_ROWS;
+                            int n, int total_blocks, const float* __restrict__ sn_state, float* __restrict__ t_out) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const float* W = params + d.w_off;
-    const float* u = sn_state + d.u_off;
-    // a wave owns rows wave, wave+4, wave+8, wave+12 and walks them TOGETHER: four independent
-    // accumulators per lane, u read once per column group, 16-B loads when Cout allows (it always does
-    // on this path: Cout % 8 == 0 except the 1-channel logit head)
-    float a[4] = {0.f, 0.f, 0.f, 0.f};
-    const float* Wr[4];
-    bool rv[4];
+    for (int blk = blockIdx.x * SN_BPW; blk < total_blocks && blk < (blockIdx.x + 1) * SN_BPW; ++blk) {
+        const int di = find_desc(descs, n, blk);
+        const NvaeConvDesc d = descs[di];
+        const int k0 = (blk - d.blk_off) * SN_ROWS;
+        const float* W = params + d.w_off;
+        const float* u = sn_state + d.u_off;
+        // a wave owns rows wave, wave+4, wave+8, wave+12 and walks them TOGETHER: four independent
+        // accumulators per lane, u read once per column group, 16-B loads when Cout allows (it always does
+        // on this path: Cout % 8 == 0 except the 1-channel logit head)
+        float a[4] = {0.f, 0.f, 0.f, 0.f};
+        const float* Wr[4];
+        bool rv[4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int k = k0 + wave + 4 * q;
-        rv[q] = k < d.K;
-        Wr[q] = W + (long)(rv[q] ? k : k0) * d.Cout;
-    }
-    if ((d.Cout & 3) == 0 && ((size_t)W & 15) == 0 && ((size_t)u & 15) == 0) {
-        for (int c = lane * 4; c < d.Cout; c += 256) {
-            const float4 uv = *(const float4*)(u + c);
+        for (int q = 0; q < 4; ++q) {
+            const int k = k0 + wave + 4 * q;
+            rv[q] = k < d.K;
+            Wr[q] = W + (long)(rv[q] ? k : k0) * d.Cout;
+        }
+        if ((d.Cout & 3) == 0 && ((size_t)W & 15) == 0 && ((size_t)u & 15) == 0) {
+            for (int c = lane * 4; c < d.Cout; c += 256) {
+                const float4 uv = *(const float4*)(u + c);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float4 w = *(const float4*)(Wr[q] + c);
-                a[q] += w.x * uv.x + w.y * uv.y + w.z * uv.z + w.w * uv.w;
+                for (int q = 0; q < 4; ++q) {
+                    const float4 w = *(const float4*)(Wr[q] + c);
+                    a[q] += w.x * uv.x + w.y * uv.y + w.z * uv.z + w.w * uv.w;
+                }
+            }
+        } else {
+            for (int c = lane; c < d.Cout; c += 64) {
+                const float uv = u[c];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) a[q] += Wr[q][c] * uv;
             }
         }
-    } else {
-        for (int c = lane; c < d.Cout; c += 64) {
-            const float uv = u[c];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) a[q] += Wr[q][c] * uv;
+        for (int q = 0; q < 4; ++q) {
+            const float v = wave_sum(a[q]);
+            if (lane == 0 && rv[q]) t_out[d.t_off + k0 + wave + 4 * q] = v;
         }
-    }
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const float v = wave_sum(a[q]);
-        if (lane == 0 && rv[q]) t_out[d.t_off + k0 + wave + 4 * q] = v;
     }
 }
 
@@ -122,7 +127,7 @@ extern "C" int nvae_sn_power_iter(float* params, const NvaeConvDesc* descs, int 
     NVAE_REQUIRE(n > 0 && total_blocks > 0 && params && descs && sn_state && sn_scratch_t && colpart && w2 && inv_sigma,
                  "sn_power_iter: bad args");
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_sn_rowdot, total_blocks, 256, 0, s, params, descs, n, sn_state, sn_scratch_t);
+    hipLaunchKernelGGL(k_sn_rowdot, cdiv(total_blocks, SN_BPW), 256, 0, s, params, descs, n, total_blocks, sn_state, sn_scratch_t);
     hipLaunchKernelGGL(k_sn_colsum, total_blocks, 256, 0, s, params, descs, n, sn_scratch_t, colpart);
     hipLaunchKernelGGL(k_sn_finish, n, 256, 0, s, descs, sn_state, sn_scratch_t, colpart, w2, inv_sigma);
     NVAE_LAUNCH_CHECK("sn_power_iter");
