@@ -135,14 +135,18 @@ def _cpu_model() -> str:
     return "unknown"
 
 
-def cpu_baseline(seconds_budget=24.0):
+def cpu_baseline(seconds_budget=24.0, workload="mnist_c2"):
     """The CPU oracle (PyTorch-CPU restatement of the reference arithmetic, f32, eager) timed on the
     host cores: same model (C2), a bounded sample of the workload (batch 8).  Two legs: all the
     cores this process may use (at most 16: the box's CPU share for one GPU), and 8 threads for comparability
-    with the 8-vCPU build container."""
+    with the 8-vCPU build container.  `--workload mnist_c1` times BASELINE.json configs[0] (the reference's
+    CPU-runnable case: groups [1,1], 1 cell) at its full batch of 32 instead."""
     from oracle.nvae_oracle import OracleConfig, OracleNVAE, synthetic_batch as sb
-    b = 8
-    orc = OracleNVAE(OracleConfig(n_groups_per_scale=[5, 10], res_cells_per_group=2), dtype=torch.float32, seed=1)
+    if workload == "mnist_c1":
+        b, ocfg = 32, OracleConfig(n_groups_per_scale=[1, 1], res_cells_per_group=1)
+    else:
+        b, ocfg = 8, OracleConfig(n_groups_per_scale=[5, 10], res_cells_per_group=2)
+    orc = OracleNVAE(ocfg, dtype=torch.float32, seed=1)
     x = sb(b, seed=1, dtype=torch.float32)
     g = torch.Generator().manual_seed(2)
     eps = [torch.randn(s, generator=g) for s in orc.eps_shapes(b)]
@@ -343,7 +347,7 @@ def main():
             "hbm_kernels": time_hbm_kernels(model, args.batch),
         }
         if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline()
+            res["cpu_baseline"] = cpu_baseline(workload="mnist_c1" if args.workload == "mnist_c1" else "mnist_c2")
         print(json.dumps(res))
     if world > 1:
         dist.destroy_process_group()

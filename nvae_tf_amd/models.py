@@ -190,7 +190,7 @@ class NVAE:
         after a tape suffix has run the gradients of everything constructed at or after its first layer are final
         (the encoder's combiner convs run inside the decoder's tape: final even earlier).  The encoder + preprocess
         range (45 % of the parameters) is cut twice at encoder group boundaries, so that the all-reduce left
-        exposed after the last kernel covers about a quarter of it (~28 MB at C2) instead of 112 MB."""
+        exposed after the last kernel covers about a quarter of it (24 MB at C2) instead of 108 MB."""
         m = self.param_marks
         segs = [(dec_mark, end, m[3], m[4]), (enc_mark, dec_mark, m[2], m[3])]
         enc = self.encoder

@@ -1,0 +1,53 @@
+"""How long does a cold microbenchmark of k_conv_halo stay representative?  Launches the dominant 5x5 layer
+back to back from an idle chip and prints the mean launch time of consecutive windows of 20 launches (HIP events on the
+launch stream) next to the shader clock / socket power rocm-smi reports at that moment.
+usage: python tools/mb_dvfs.py [windows]"""
+import ctypes as C, json, os, subprocess, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from nvae_tf_amd import _lib as L
+from nvae_tf_amd.ops import same_pad
+
+dev = "cuda:0"
+lib = L.load()
+B, H, ci, co, k = 128, 16, 384, 384, 5
+p = same_pad(H, k, 1)[0]
+g = L.ConvGeom(B, H, H, ci, H, H, co, k, k, 1, p, p, 1, 0, ci, co, co)
+x = torch.randn(B, H, H, ci, device=dev).bfloat16()
+w = (torch.randn(co, k * k * ci, device=dev) * 0.05).bfloat16()
+out = torch.empty(B, H, H, co, device=dev, dtype=torch.bfloat16)
+fn = lambda: L.call("nvae_conv_gemm", L.BF16, C.byref(g), L.ptr(x), L.ptr(w), k * k * ci, None, None, L.ptr(out), 0, None)
+fn(); torch.cuda.synchronize()
+gr = torch.cuda.CUDAGraph()
+with torch.cuda.graph(gr):
+    for _ in range(20):
+        fn()
+
+
+def smi():
+    try:
+        o = subprocess.run(["rocm-smi", "--showclocks", "--showpower", "--json"], capture_output=True, text=True, timeout=20).stdout
+        d = json.loads(o)
+        card = d[sorted(d)[0]]
+        return {k: v for k, v in card.items() if "sclk" in k.lower() or "power" in k.lower()}
+    except Exception as e:      # noqa
+        return {"rocm-smi": repr(e)[:80]}
+
+
+n_win = int(sys.argv[1]) if len(sys.argv) > 1 else 400
+print("idle:", smi(), flush=True)
+time.sleep(2.0)
+ev = [torch.cuda.Event(enable_timing=True) for _ in range(n_win + 1)]
+ev[0].record()
+for i in range(n_win):
+    gr.replay()
+    ev[i + 1].record()
+t_smi = smi()                      # sampled while the queue is still draining
+torch.cuda.synchronize()
+us = [ev[i].elapsed_time(ev[i + 1]) * 1000 / 20 for i in range(n_win)]
+flop = 2.0 * B * H * H * co * k * k * ci
+cum = 0.0
+for i in (0, 1, 2, 3, 5, 8, 12, 20, 30, 50, 80, 120, 200, 300, n_win - 1):
+    if i < n_win:
+        print(f"window {i:4d} (t = {sum(us[:i]) * 20 / 1000:7.1f} ms): {us[i]:6.1f} us/launch = {flop / us[i] / 1e6:7.1f} TFLOP/s")
+print("under load:", t_smi)

@@ -4,7 +4,10 @@ and the gap of the trailing-window means.  usage: python tools/soak_pair.py [wor
 The two runs start bit-identical (f32 master weights, identical Philox noise) and drift apart chaotically, as any
 two roundings of the same training run do; what must hold is that bf16 optimises the same objective equally
 well: the ELBO levels (means over a trailing window of steps, and a fixed held-out batch under fixed noise at the
-end) agree within the tolerance north_star allows (0.5 nats)."""
+end) agree within the run-to-run spread of f32 training itself.  That spread is measured by the CONTROL pair:
+the same two models again, same initial weights and data, only the Philox key of the in-graph noise differs
+(tags "bf16/B", "f32/B"); |f32 - f32/B| is what two equally valid f32 runs differ by.
+  NVAE_SOAK_CONTROL=0 skips the control pair."""
 import json, math, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -25,8 +28,12 @@ data = torch.zeros(B * (nb + 1), 32, 32, 1); data[:, 2:30, 2:30, 0] = (raw > 0).
 data = data.to(dev)
 held_out = data[nb * B:(nb + 1) * B]
 models = {}
-for tag, dt in (("bf16", torch.bfloat16), ("f32", torch.float32)):
+runs = [("bf16", torch.bfloat16, 1), ("f32", torch.float32, 1)]
+if os.environ.get("NVAE_SOAK_CONTROL", "1") != "0":
+    runs += [("bf16/B", torch.bfloat16, 1001), ("f32/B", torch.float32, 1001)]
+for tag, dt, noise_key in runs:
     m = configs.build(name, batch=B, device=dev, dtype=dt, total_epochs=1, n_total_iterations=steps, seed=1)
+    m.seed = noise_key                      # after construction: the weights are those of seed 1 in every run
     m.capture_train_step((B, H, W, C))
     models[tag] = m
 assert torch.equal(models["bf16"].ps.params, models["f32"].ps.params)
@@ -61,6 +68,13 @@ for tag, m in models.items():
     res[tag]["held_out_neg_elbo"] = float((rec + lq - lp).mean())
 res["gap_trailing_nats"] = res["bf16"]["neg_elbo_trailing_mean"] - res["f32"]["neg_elbo_trailing_mean"]
 res["gap_held_out_nats"] = res["bf16"]["held_out_neg_elbo"] - res["f32"]["held_out_neg_elbo"]
+if "f32/B" in res:
+    res["control_f32_vs_f32_trailing_nats"] = res["f32/B"]["neg_elbo_trailing_mean"] - res["f32"]["neg_elbo_trailing_mean"]
+    res["control_f32_vs_f32_held_out_nats"] = res["f32/B"]["held_out_neg_elbo"] - res["f32"]["held_out_neg_elbo"]
+    res["gap_B_trailing_nats"] = res["bf16/B"]["neg_elbo_trailing_mean"] - res["f32/B"]["neg_elbo_trailing_mean"]
+    res["gap_B_held_out_nats"] = res["bf16/B"]["held_out_neg_elbo"] - res["f32/B"]["held_out_neg_elbo"]
+    res["bf16_mean_minus_f32_mean_trailing_nats"] = 0.5 * (res["gap_trailing_nats"] + res["gap_B_trailing_nats"])
+    res["bf16_mean_minus_f32_mean_held_out_nats"] = 0.5 * (res["gap_held_out_nats"] + res["gap_B_held_out_nats"])
 print(json.dumps(res, indent=1))
 if out_json:
     with open(out_json, "w") as fh:
