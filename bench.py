@@ -220,13 +220,16 @@ def side_workload(args):
         out = step()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    print(json.dumps({"metric": "train_images_per_sec", "value": batch * args.steps / dt, "unit": "images/s",
-                      "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-                      "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-                      "dtype": args.dtype, "data": "synthetic",
-                      "config": {"workload": args.workload, "global_batch": batch, "groups": c["n_groups_per_scale"],
-                                 "parameters": model.n_trainable(), "hip_graph": not args.no_graph},
-                      "loss_nats": float(out["loss"]), "roofline": None}))
+    res = {"metric": "train_images_per_sec", "value": batch * args.steps / dt, "unit": "images/s",
+           "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": args.dtype, "data": "synthetic",
+           "config": {"workload": args.workload, "global_batch": batch, "groups": c["n_groups_per_scale"],
+                      "parameters": model.n_trainable(), "hip_graph": not args.no_graph},
+           "loss_nats": float(out["loss"]), "roofline": None}
+    if args.workload == "mnist_c1" and not args.no_cpu_baseline:
+        res["cpu_baseline"] = cpu_baseline(workload="mnist_c1")     # BASELINE.json configs[0] at its own batch of 32
+    print(json.dumps(res))
 
 
 def main():

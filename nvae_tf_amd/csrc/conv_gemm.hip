@@ -456,6 +456,36 @@ __global__ __launch_bounds__(WM* WN * 64) void k_conv_gemm2(
         // refill the slot that was read in step t-1 with the tile of step t + STAGES - 1
         if (t + STAGES - 1 < nk) issue(cur >= 1 ? cur - 1 : STAGES - 1);
         const uint4* buf = lds + cur * STAGE;
+        if constexpr (sizeof(T) == 4) {
+            // f32 (the parity path): TWO-LEVEL accumulation.  One accumulator fed K products in K order carries a
+            // rounding error ~ eps * K / sqrt(2) (in units of the products' spread); K is 2 304-9 600 here, and measured
+            // against fp64 that was 3-5x the error of a blocked CPU GEMM (tools/diag_f32_ops.py).  Each ring step's
+            // 32 / 64 products are summed in a fresh accumulator and added to the running one: error ~ eps *
+            // sqrt(c*K/2 + K^2/(2c)), 5-7x smaller at these K.
+            uint4 af[BKC / 4][MI], bf[BKC / 4][NI];
+#pragma unroll
+            for (int h = 0; h < BKC / 4; ++h) {
+#pragma unroll
+                for (int i = 0; i < MI; ++i) {
+                    int r = wm * (BM / WM) + i * 16 + fr;
+                    af[h][i] = buf[r * BKC + ((h * 4 + fq) ^ swz_row<BKC>(r))];
+                }
+#pragma unroll
+                for (int j = 0; j < NI; ++j) {
+                    int r = wn * (BN / WN) + j * 16 + fr;
+                    bf[h][j] = buf[BM * BKC + r * BKC + ((h * 4 + fq) ^ swz_row<BKC>(r))];
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j) {
+                    f32x4 part = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int h = 0; h < BKC / 4; ++h) mfma_step<T>(af[h][i], bf[h][j], part);
+                    acc[i][j] += part;
+                }
+        } else {
 #pragma unroll
         for (int h = 0; h < BKC / 4; ++h) {
             uint4 af[MI], bf[NI];
@@ -473,6 +503,7 @@ __global__ __launch_bounds__(WM* WN * 64) void k_conv_gemm2(
             for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int j = 0; j < NI; ++j) mfma_step<T>(af[i], bf[j], acc[i][j]);
+        }
         }
         cur = cur == STAGES - 1 ? 0 : cur + 1;
     }
@@ -693,6 +724,32 @@ __global__ __launch_bounds__(WM * 128) void k_conv_halo(
                 for (int i = 0; i < MI; ++i)
 #pragma unroll
                     for (int j = 0; j < NI; ++j) mfma_step<T>(af[h][i], bf[h][j], acc[i][j]);
+        } else if constexpr (sizeof(T) == 4) {
+            // f32: two-level accumulation, one partial per (tap, 32-channel chunk) -- see k_conv_gemm2
+            prefetch(s, tap, cc);
+            uint4 af[2][MI], bf[2][NI];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+#pragma unroll
+                for (int i = 0; i < MI; ++i) {
+                    const int hrow = (wm * MI + i + kh) * HP + kw + fr;
+                    af[h][i] = abuf[hrow * 8 + ((h * 4 + fq) ^ (hrow & 7))];
+                }
+#pragma unroll
+                for (int j = 0; j < NI; ++j) {
+                    const int r = wn * (BN / WN) + j * 16 + fr;
+                    bf[h][j] = bbuf[r * 8 + ((h * 4 + fq) ^ (r & 7))];
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j) {
+                    f32x4 part = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    mfma_step<T>(af[0][i], bf[0][j], part);
+                    mfma_step<T>(af[1][i], bf[1][j], part);
+                    acc[i][j] += part;
+                }
         } else {
             prefetch(s, tap, cc);
 #pragma unroll

@@ -51,3 +51,35 @@ for i in (0, 1, 2, 3, 5, 8, 12, 20, 30, 50, 80, 120, 200, 300, n_win - 1):
     if i < n_win:
         print(f"window {i:4d} (t = {sum(us[:i]) * 20 / 1000:7.1f} ms): {us[i]:6.1f} us/launch = {flop / us[i] / 1e6:7.1f} TFLOP/s")
 print("under load:", t_smi)
+
+# --- the training step's duty pattern: short MFMA bursts between phases of small kernels.  Graph A = 6 launches of the
+# 5x5 layer + 300 tiny elementwise kernels (~1.5 ms), graph B = the 300 tiny kernels alone; both replayed 100 times back
+# to back; (A - B) / 6 is what a launch of the big kernel costs inside that pattern.
+small = torch.randn(1 << 16, device=dev).bfloat16()
+small_o = torch.empty_like(small)
+tiny = lambda: L.call("nvae_unary_fwd", L.BF16, 2, L.ptr(small), L.ptr(small_o), small.numel(), 1.0, 0.0)
+try:
+    tiny(); torch.cuda.synchronize()
+    ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+    with torch.cuda.graph(ga):
+        for _ in range(6):
+            fn()
+        for _ in range(300):
+            tiny()
+    with torch.cuda.graph(gb):
+        for _ in range(300):
+            tiny()
+    def run(gr, n=100):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n):
+            gr.replay()
+        e1.record(); torch.cuda.synchronize()
+        return e0.elapsed_time(e1) * 1000 / n
+    time.sleep(1.0)
+    for rnd in range(3):
+        tb = run(gb); ta = run(ga)
+        print(f"duty pattern round {rnd}: graph A {ta:8.1f} us, graph B (300 tiny kernels) {tb:8.1f} us -> {(ta - tb) / 6:6.1f} us per 5x5 launch "
+              f"= {flop / ((ta - tb) / 6) / 1e6:7.1f} TFLOP/s", flush=True)
+except Exception as e:      # noqa
+    print("duty pattern skipped:", repr(e)[:200])

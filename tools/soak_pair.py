@@ -66,6 +66,22 @@ for tag, m in models.items():
     logits, zp, lp, lq = m(held_out, nll=True, eps_list=eps)
     rec = m.calculate_recon_loss(held_out, logits)
     res[tag]["held_out_neg_elbo"] = float((rec + lq - lp).mean())
+# the same TRAINED weights evaluated in the other precision: isolates what bf16 arithmetic does to the ELBO of a given
+# model from where chaotic training happened to take each run
+def held_out_with(weights_of, run_in):
+    src, dst = models[weights_of], models[run_in]
+    keep = (dst.ps.params.clone(), dst.ps.state.clone())
+    dst.ps.params.copy_(src.ps.params); dst.ps.state.copy_(src.ps.state)
+    logits, zp, lp, lq = dst(held_out, nll=True, eps_list=eps)
+    v = float((dst.calculate_recon_loss(held_out, logits) + lq - lp).mean())
+    dst.ps.params.copy_(keep[0]); dst.ps.state.copy_(keep[1])
+    return v
+res["cross_precision_held_out"] = {
+    "f32_weights_in_f32": res["f32"]["held_out_neg_elbo"], "f32_weights_in_bf16": held_out_with("f32", "bf16"),
+    "bf16_weights_in_bf16": res["bf16"]["held_out_neg_elbo"], "bf16_weights_in_f32": held_out_with("bf16", "f32")}
+c = res["cross_precision_held_out"]
+res["bf16_inference_minus_f32_inference_nats"] = [c["f32_weights_in_bf16"] - c["f32_weights_in_f32"],
+                                                  c["bf16_weights_in_bf16"] - c["bf16_weights_in_f32"]]
 res["gap_trailing_nats"] = res["bf16"]["neg_elbo_trailing_mean"] - res["f32"]["neg_elbo_trailing_mean"]
 res["gap_held_out_nats"] = res["bf16"]["held_out_neg_elbo"] - res["f32"]["held_out_neg_elbo"]
 if "f32/B" in res:
