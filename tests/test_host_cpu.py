@@ -137,3 +137,22 @@ def test_grad_reducer_gloo_world2():
         assert abs(tot - 1.5 * n * (n - 1) / 2) / tot < 1e-6
         assert am == [1.5, 3.0, 4.5]
         assert first_stop == n and last_start == 0 and covered == n   # end of the buffer first
+
+
+def test_torch_library_registration():
+    """`torch.ops.nvae.*` exist, their fake implementations give the output shapes, and there is no CPU kernel behind
+    them (the dispatcher raises instead of falling back)."""
+    import nvae_tf_amd.torch_ops      # noqa: F401
+    ops = torch.ops.nvae
+    x = torch.empty(2, 8, 8, 32, device="meta", dtype=torch.bfloat16)
+    w = torch.empty(3, 3, 32, 64, device="meta")
+    assert ops.conv2d_same(x, w, None).shape == (2, 8, 8, 64) and ops.conv2d_same(x, w, None).dtype == torch.bfloat16
+    assert ops.dwconv5(x, torch.empty(5, 5, 32, device="meta"), torch.empty(32, device="meta")).shape == x.shape
+    y, mean, invstd = ops.bn_act(x, torch.empty(32, device="meta"), torch.empty(32, device="meta"), 1, 1e-5)
+    assert y.shape == x.shape and mean.shape == (32,) and invstd.shape == (32,)
+    out = ops.se_residual(x, x, torch.empty(32, 4, device="meta"), torch.empty(4, device="meta"),
+                          torch.empty(4, 32, device="meta"), torch.empty(32, device="meta"), 1.0, 0.1)
+    assert out[0].shape == x.shape and out[2].shape == (2, 32) and out[3].shape == (2, 4)
+    assert ops.bernoulli_nll(torch.empty(2, 32, 32, 1, device="meta"), torch.empty(2, 32, 32, 1, device="meta")).shape == (2,)
+    with pytest.raises(NotImplementedError):
+        ops.conv2d_same(torch.zeros(2, 8, 8, 32), torch.zeros(3, 3, 32, 64), None)

@@ -7,7 +7,14 @@ atomics-ordered reductions make even two runs of the SAME configuration diverge)
 f32" is not a resolvable statement about a pair of training runs.  What bf16 arithmetic does to the ELBO of a GIVEN
 model is: the same trained weights evaluated in both precisions on a held-out batch with fixed noise.  That is the
 0.5-nat bound (north_star: "NLL within +-0.5 nats") asserted here; the training curves are asserted to stay together at
-the scale of their own run-to-run spread."""
+the scale of their own run-to-run spread.
+
+The evaluation here uses BATCH statistics: this early in training (500 steps, KL still ~100 nats) the moving
+BatchNorm statistics (Keras momentum 0.05: essentially the last training batch's) make the eval-mode forward of a
+held-out batch wildly off in ANY precision (tools/diag_precision.py: -ELBO 9e4 at step 240, 600 at step 600 against
+500 with batch statistics), so its bf16-f32 difference says nothing about arithmetic.  Measured there (batch 64):
+batch-statistics difference -0.17 / +0.29 nats at step 240, -0.05 / -0.02 at 600, -0.02 / +0.002 at 1 200; eval-mode
+difference -0.007 / -0.001 at 1 200 and -0.007 / -0.067 after the 3 000-step soak."""
 import math
 
 import pytest
@@ -15,13 +22,13 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-STEPS, BATCH, WINDOW = 240, 64, 40
+STEPS, BATCH, WINDOW = 500, 64, 50
 
 
 def test_bf16_training_tracks_f32(lib, dev):
     from nvae_tf_amd import configs
     from nvae_tf_amd.datasets import synthetic_mnist
-    nb = 8
+    nb = 32
     raw = torch.from_numpy(synthetic_mnist(BATCH * (nb + 1), 1)[0]).float()
     data = torch.zeros(BATCH * (nb + 1), 32, 32, 1)
     data[:, 2:30, 2:30, 0] = (raw > 0).float()
@@ -46,18 +53,18 @@ def test_bf16_training_tracks_f32(lib, dev):
     torch.cuda.synchronize()
     mean = {t: (sum(r for r, _ in v) / len(v), sum(k for _, k in v) / len(v)) for t, v in tail.items()}
     print("trailing means (recon, KL):", mean)
-    # the curves stay together: reconstruction within 1.5 %, negative ELBO within 6 % (the KL term is still falling by
-    # ~1 nat per step here, so the two runs are a few steps apart, not at different levels)
+    # the curves stay together: reconstruction within 1.5 %, negative ELBO within 8 % (the KL term is still falling by
+    # ~0.3 nats per step here, so the two runs are some tens of steps apart, not at different levels)
     assert abs(mean["bf16"][0] - mean["f32"][0]) / mean["f32"][0] < 0.015
     nelbo = {t: mean[t][0] + mean[t][1] for t in mean}
-    assert abs(nelbo["bf16"] - nelbo["f32"]) / nelbo["f32"] < 0.06
+    assert abs(nelbo["bf16"] - nelbo["f32"]) / nelbo["f32"] < 0.08
 
-    # the same weights in both precisions: held-out single-sample negative ELBO under fixed noise
+    # the same weights in both precisions: held-out single-sample negative ELBO under fixed noise, batch statistics
     g = torch.Generator().manual_seed(77)
     eps = [torch.randn(s, generator=g) for s in models["f32"].eps_shapes(BATCH)]
 
     def neg_elbo(m):
-        logits, _, lp, lq = m(held_out, nll=True, eps_list=eps)
+        logits, _, lp, lq = m(held_out, nll=True, eps_list=eps, training=True)
         return float((m.calculate_recon_loss(held_out, logits) + lq - lp).mean())
 
     for weights_of in ("f32", "bf16"):
@@ -69,4 +76,4 @@ def test_bf16_training_tracks_f32(lib, dev):
             vals[run_in] = neg_elbo(m)
             m.ps.params.copy_(keep[0]); m.ps.state.copy_(keep[1])
         print(f"weights trained in {weights_of}: held-out -ELBO in f32 {vals['f32']:.3f}, in bf16 {vals['bf16']:.3f}")
-        assert abs(vals["bf16"] - vals["f32"]) < 0.5, (weights_of, vals)
+        assert abs(vals["bf16"] - vals["f32"]) < 0.5 and abs(vals["bf16"] - vals["f32"]) < 1e-3 * vals["f32"], (weights_of, vals)

@@ -58,28 +58,30 @@ print("under load:", t_smi)
 small = torch.randn(1 << 16, device=dev).bfloat16()
 small_o = torch.empty_like(small)
 tiny = lambda: L.call("nvae_unary_fwd", L.BF16, 2, L.ptr(small), L.ptr(small_o), small.numel(), 1.0, 0.0)
-try:
-    tiny(); torch.cuda.synchronize()
+def run(gr, n):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        gr.replay()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1000 / n
+
+
+tiny(); torch.cuda.synchronize()
+for n_tiny in (300, 1500, 6000):
     ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
     with torch.cuda.graph(ga):
         for _ in range(6):
             fn()
-        for _ in range(300):
+        for _ in range(n_tiny):
             tiny()
     with torch.cuda.graph(gb):
-        for _ in range(300):
+        for _ in range(n_tiny):
             tiny()
-    def run(gr, n=100):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(n):
-            gr.replay()
-        e1.record(); torch.cuda.synchronize()
-        return e0.elapsed_time(e1) * 1000 / n
-    time.sleep(1.0)
-    for rnd in range(3):
-        tb = run(gb); ta = run(ga)
-        print(f"duty pattern round {rnd}: graph A {ta:8.1f} us, graph B (300 tiny kernels) {tb:8.1f} us -> {(ta - tb) / 6:6.1f} us per 5x5 launch "
-              f"= {flop / ((ta - tb) / 6) / 1e6:7.1f} TFLOP/s", flush=True)
-except Exception as e:      # noqa
-    print("duty pattern skipped:", repr(e)[:200])
+    time.sleep(0.5)
+    reps = max(30000 // n_tiny, 10)
+    for rnd in range(2):
+        tb = run(gb, reps); ta = run(ga, reps)
+        per = (ta - tb) / 6
+        print(f"duty pattern, 6 big + {n_tiny:5d} tiny kernels, round {rnd}: A {ta:9.1f} us, B {tb:9.1f} us ({tb / n_tiny:5.2f} us per tiny kernel) -> "
+              f"{per:6.1f} us per 5x5 launch = {flop / per / 1e6:7.1f} TFLOP/s (MFMA duty {6 * per / ta * 100:4.1f} %)", flush=True)

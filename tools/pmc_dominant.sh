@@ -16,7 +16,8 @@ python tools/make_pmc_util_json.py gpurun_out/pmc_${tag}_util gpurun_out/${tag}_
 python tools/make_pmc_json.py gpurun_out/pmc_${tag}_fetch gpurun_out/pmc_${tag}_write gpurun_out/${tag}_pmc_dominant.json k_conv_halo > /dev/null
 for d in util fetch write; do
   f=$(ls gpurun_out/pmc_${tag}_$d/*/*counter_collection.csv gpurun_out/pmc_${tag}_$d/*counter_collection.csv 2>/dev/null | head -1)
-  [ -n "$f" ] && grep -E "Counter_Name|k_conv_halo|k_wgrad_halo" "$f" | cut -d, -f1-20 > gpurun_out/${tag}_pmc_${d}.csv
+  [ -n "$f" ] && grep -E "Counter_Name|halo" "$f" > gpurun_out/${tag}_pmc_${d}.csv
+  [ -n "$f" ] && cut -d, -f9 "$f" | cut -c1-60 | sort | uniq -c > gpurun_out/${tag}_pmc_${d}_kernels.txt
   rm -rf gpurun_out/pmc_${tag}_$d
 done
 grep -h "mfma_util\|frac_\|ratio" gpurun_out/${tag}_pmc_wave_states.json gpurun_out/${tag}_pmc_wgrad_wave_states.json gpurun_out/${tag}_pmc_dominant.json
