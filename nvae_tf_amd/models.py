@@ -7,6 +7,7 @@ one spectral-norm power iteration per conv; call/sample run moving-statistics BN
 from __future__ import annotations
 
 import math
+import os
 from typing import Dict, List, Optional
 
 import numpy as np
@@ -23,6 +24,9 @@ from .postprocess import Postprocess
 from .preprocess import Preprocess
 
 ADAMAX_B1, ADAMAX_B2, ADAMAX_EPS = 0.9, 0.999, 1e-7   # Keras Adamax defaults [3P], train.py:131
+# single-GPU overlap of the step's HBM-bound bookkeeping with its launch-bound compute (both default on):
+OVERLAP_PREP = os.environ.get("NVAE_OVERLAP_PREP", "1") != "0"      # SN + weight copies of later modules on the side stream
+OVERLAP_ADAMAX = os.environ.get("NVAE_OVERLAP_ADAMAX", "1") != "0"  # Adamax of a finished backward segment on the side stream
 
 
 class NVAE:
@@ -58,21 +62,22 @@ class NVAE:
         ps = ParamStore(seed)
         self.ps = ps
         marks = [0]             # flat-buffer offsets where preprocess / encoder / decoder / postprocess end
+        cmarks = [0]            # the same boundaries as indices into ps.convs (ParamStore.prepare_weights(part=k))
         self.preprocess = Preprocess(ps, n_encoder_channels, n_preprocess_blocks, n_preprocess_cells,
                                      scale_factor, input_shape)
         mult = self.preprocess.mult
-        marks.append(ps._p_cursor)
+        marks.append(ps._p_cursor); cmarks.append(len(ps.convs))
         self.encoder = Encoder(ps, n_encoder_channels, n_decoder_channels, n_latent_per_group,
                                res_cells_per_group, n_latent_scales, self.n_groups_per_scale, mult,
                                scale_factor, self.preprocess.output_shape_)
         mult = self.encoder.mult
-        marks.append(ps._p_cursor)
+        marks.append(ps._p_cursor); cmarks.append(len(ps.convs))
         self.decoder = Decoder(ps, n_encoder_channels, n_decoder_channels, n_latent_per_group,
                                res_cells_per_group, n_latent_scales,
                                list(reversed(self.n_groups_per_scale)), mult, scale_factor,
                                self.encoder.output_shape_)
         mult = self.decoder.mult
-        marks.append(ps._p_cursor)
+        marks.append(ps._p_cursor); cmarks.append(len(ps.convs))
         self.head = head or ("bernoulli" if input_shape[3] == 1 else "dmol")
         assert self.head in ("bernoulli", "dmol")
         assert self.head == "bernoulli" or input_shape[3] == 3, "the mixture-of-logistics head models RGB"
@@ -80,8 +85,9 @@ class NVAE:
         out_channels = input_shape[3] if self.head == "bernoulli" else 10 * self.num_mixture_dec
         self.postprocess = Postprocess(ps, n_postprocess_blocks, n_post_process_cells, mult,
                                        n_decoder_channels, scale_factor, out_channels=out_channels)
-        marks.append(ps._p_cursor)
+        marks.append(ps._p_cursor); cmarks.append(len(ps.convs))
         self.param_marks = marks
+        ps.prep_marks = cmarks
         self.n_groups = self.decoder.n_groups
         # per-image activation footprint decides the scratch pool; generous fixed size
         ps.finalize(self.device, dtype, zero_pool_floats=1 << 24)
@@ -169,16 +175,19 @@ class NVAE:
             L.call("nvae_cast", L.F32, ctx.dt, L.ptr(x), L.ptr(xin), x.numel())
             x = xin
         h = self.preprocess(ctx, x)
+        self._await_weights(1)
         enc_dec_combiners, final_x = self.encoder(ctx, h)
         enc_mark = len(ctx.tape)
         enc_dec_combiners.reverse()    # bottom-up -> top-down, models.py:93
         if nll:
             buf["log_p"].zero_(); buf["log_q"].zero_()
+        self._await_weights(2)
         s = self.decoder(ctx, final_x, enc_dec_combiners, eps, buf["kl_all"], self.coeff, self.hyper,
                          1.0 / B, nll=nll, log_p=buf["log_p"], log_q=buf["log_q"],
                          mu_sigma_list=mu_sigma_list)
         self._tape_marks = (enc_mark, len(ctx.tape))
         dec_mark = len(ctx.tape)
+        self._await_weights(3)
         logits = self.postprocess(ctx, s)
         if ctx.record:
             self._segments = self._make_segments(enc_mark, dec_mark, len(ctx.tape))
@@ -302,10 +311,9 @@ class NVAE:
         ps = self.ps
         B = x.shape[0]
         buf = self._buffers(B)
-        ps.begin_step()
-        ps.prepare_weights(spectral_norm=spectral_norm and not self.tf_literal)
         if self.overlap_wgrad and self._side is None and self.device.type == "cuda":
             self._side = torch.cuda.Stream(device=self.device)
+        self._prepare_weights_staged(spectral_norm and not self.tf_literal)
         ctx = Ctx(ps, self.dtype, training=not self.tf_literal, record=True,
                   side_stream=self._side if self.overlap_wgrad else None)
         self._bn_loss = ctx.zeros_f32(1)
@@ -322,10 +330,39 @@ class NVAE:
         self._logits = logits
         return ctx
 
+    def _prepare_weights_staged(self, sn: bool):
+        """Per-step zeroing, spectral norm + compute copies (1.7 GB of HBM traffic per step at C2, 0.8 ms).  Only the preprocess convs
+        are prepared on the main stream; the encoder / decoder / postprocess parts run on the side stream, in the
+        order the forward pass needs them, while the earlier modules already compute (`_await_weights` makes the
+        main stream wait for a part just before its module starts).  The parts touch disjoint slices of every
+        buffer involved (masters, SN vectors and scratch, copies)."""
+        ps = self.ps
+        self._prep_events = {}
+        if not (OVERLAP_PREP and self.overlap_wgrad and self._side is not None and ps.n_prep_parts() == 4):
+            ps.begin_step()
+            ps.prepare_weights(spectral_norm=sn)
+            return
+        main = torch.cuda.current_stream()
+        self._side.wait_stream(main)
+        ps.begin_step(zero_grads=False)
+        ps.prepare_weights(spectral_norm=sn, part=0)
+        with torch.cuda.stream(self._side):
+            ps.grads.zero_()                 # 250 MB memset: needed by the backward pass only
+            for k in (1, 2, 3):
+                ps.prepare_weights(spectral_norm=sn, part=k)
+                ev = torch.cuda.Event()
+                ev.record(self._side)
+                self._prep_events[k] = ev
+
+    def _await_weights(self, part: int):
+        ev = getattr(self, "_prep_events", {}).pop(part, None)
+        if ev is not None:
+            torch.cuda.current_stream().wait_event(ev)
+
     def n_segments(self) -> int:
         return len(self._segments)
 
-    def _seg_backward(self, ctx: Ctx, B: int, part: Optional[int] = None):
+    def _seg_backward(self, ctx: Ctx, B: int, part: Optional[int] = None, join: bool = True):
         """Loss + backward.  part=None: everything.  part k: segment k of `self._segments` (postprocess, decoder,
         then the encoder + preprocess pieces; run in that order); after part k the gradients of flat-buffer
         range `self.grad_range(k)` are final."""
@@ -343,7 +380,7 @@ class NVAE:
             ctx.backward()
         else:
             lo, hi = self._segments[part][:2]
-            ctx.backward(lo, hi if part else None)      # (the loss ops appended after the forward pass belong to segment 0)
+            ctx.backward(lo, hi if part else None, join=join)      # (the loss ops appended after the forward pass belong to segment 0)
 
     def grad_range(self, part: int):
         """Flat gradient range completed by backward segment `part` (see _make_segments)."""
@@ -361,10 +398,25 @@ class NVAE:
     def _dp_segments(self) -> bool:
         return self.reducer is not None and self.overlap_allreduce
 
-    def _seg_update(self):
+    def _seg_update(self, lo: int = 0, hi: Optional[int] = None):
         ps = self.ps
-        L.call("nvae_adamax", L.ptr(ps.params), L.ptr(ps.grads), L.ptr(ps.adam_m), L.ptr(ps.adam_u),
-               ps.params.numel(), L.ptr(self.hyper), ADAMAX_B1, ADAMAX_B2, ADAMAX_EPS)
+        hi = ps.params.numel() if hi is None else hi
+        if hi > lo:
+            L.call("nvae_adamax", L.ptr(ps.params) + 4 * lo, L.ptr(ps.grads) + 4 * lo, L.ptr(ps.adam_m) + 4 * lo,
+                   L.ptr(ps.adam_u) + 4 * lo, hi - lo, L.ptr(self.hyper), ADAMAX_B1, ADAMAX_B2, ADAMAX_EPS)
+
+    def _fused_update(self) -> bool:
+        """Single GPU: no collective stands between a backward segment and its optimizer step, so the Adamax launch
+        of a finished segment's parameter range goes onto the side stream behind that segment's weight gradients
+        and runs under the next segment's data-gradient chain (0.3 ms of HBM-bound work per step at C2)."""
+        return OVERLAP_ADAMAX and self.reducer is None and self.overlap_wgrad and self._side is not None
+
+    def _backward_with_update(self, ctx: Ctx, B: int):
+        for part in range(self.n_segments()):
+            self._seg_backward(ctx, B, part, join=False)
+            lo, hi = self.grad_range(part)
+            ctx.fork(lambda lo=lo, hi=hi: self._seg_update(lo, hi))
+        ctx.join_side()
 
     def train_step(self, data, eps_list=None, spectral_norm=True, update=True):
         """NVAE.train_step, models.py:100-135 (eager launch path).  Returns device tensors:
@@ -376,18 +428,22 @@ class NVAE:
         ctx = self._seg_forward(x, eps_list, spectral_norm)
         if self.reducer is not None:
             self.reducer.allreduce_mean_(self.am)
+        fused = update and self._fused_update()
         if self._dp_segments():
             works = []
             for part in range(self.n_segments()):
                 self._seg_backward(ctx, B, part)
                 self.reducer.start_allreduce_(self.ps.grads, *self.grad_range(part), works)
             self.reducer.finish_allreduce_(works)
+        elif fused:
+            self._backward_with_update(ctx, B)
         else:
             self._seg_backward(ctx, B)
             if self.reducer is not None:
                 self.reducer.allreduce_grads_(self.ps.grads)
         if update:
-            self._seg_update()
+            if not fused:
+                self._seg_update()
             self.opt_iterations += 1
         self.steps += 1
         return self._step_outputs(B)
@@ -425,8 +481,11 @@ class NVAE:
         with torch.cuda.stream(side):
             for _ in range(warmup):
                 ctx = self._seg_forward(self._static_x, None)
-                self._seg_backward(ctx, B)
-                self._seg_update()
+                if self._fused_update():
+                    self._backward_with_update(ctx, B)
+                else:
+                    self._seg_backward(ctx, B)
+                    self._seg_update()
             for t, saved in snap:
                 t.copy_(saved)
         torch.cuda.current_stream().wait_stream(side)
@@ -444,12 +503,18 @@ class NVAE:
                 g2.append(torch.cuda.CUDAGraph())
                 with torch.cuda.graph(g2[-1], **kw):
                     self._seg_backward(ctx, B, part)
+        elif self._fused_update():
+            g2 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g2, **kw):
+                self._backward_with_update(ctx, B)
+            g3 = None                       # the optimizer step is part of the backward graph
         else:
             g2 = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g2, **kw):
                 self._seg_backward(ctx, B)
-        with torch.cuda.graph(g3, **kw):
-            self._seg_update()
+        if g3 is not None:
+            with torch.cuda.graph(g3, **kw):
+                self._seg_update()
         self._plan = (g1, g2, g3, B)
         return self
 
@@ -472,7 +537,8 @@ class NVAE:
             g2.replay()
             if self.reducer is not None:
                 self.reducer.allreduce_grads_(self.ps.grads)
-        g3.replay()
+        if g3 is not None:
+            g3.replay()
         self.opt_iterations += 1
         self.steps += 1
         return self._step_outputs(B)

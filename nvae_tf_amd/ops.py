@@ -225,17 +225,34 @@ class Ctx:
                 fn()
         self.deferred.clear()
 
-    def backward(self, lo: int = 0, hi: Optional[int] = None):
+    def backward(self, lo: int = 0, hi: Optional[int] = None, join: bool = True):
         """Run the tape entries [lo, hi) in reverse and join the side stream, so that every gradient
         those entries produce is complete on the current stream.  backward() runs the whole tape;
-        data-parallel steps run it in segments and all-reduce each segment's parameters meanwhile."""
+        data-parallel steps run it in segments and all-reduce each segment's parameters meanwhile.
+        join=False leaves the queued side-stream work forked (the caller continues on the side stream with
+        `fork` and joins once at the end with `join_side`)."""
         hi = len(self.tape) if hi is None else hi
         for fn in reversed(self.tape[lo:hi]):
             fn()
         self.flush_side()
-        if self.side is not None:
-            torch.cuda.current_stream().wait_stream(self.side)   # join before the optimizer / all-reduce
+        if join:
+            self.join_side()
         del self.tape[lo:hi]
+        if not self.tape and join:
+            self.keep.clear()
+
+    def fork(self, fn: Callable[[], None]):
+        """Run fn on the side stream after everything issued so far on either stream."""
+        if self.side is None:
+            fn()
+            return
+        self.side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self.side):
+            fn()
+
+    def join_side(self):
+        if self.side is not None:
+            torch.cuda.current_stream().wait_stream(self.side)
         if not self.tape:
             self.keep.clear()
 

@@ -186,6 +186,21 @@ class ParamStore:
         self.wcopies = torch.zeros(max(cursor, 16), dtype=dtype, device=device)
         raw = bytes(descs) or bytes(8)
         self.descs = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(device)
+        # per-module descriptor tables (prepare_weights(part=k)): the same descriptors with the workgroup numbering
+        # rebased to the part's first conv, so that a part is an ordinary launch of the multi-tensor kernels
+        self._parts = []
+        marks = getattr(self, "prep_marks", None)
+        if marks and len(self.convs):
+            assert marks[0] == 0 and marks[-1] == len(self.convs) and list(marks) == sorted(marks)
+            reb = (L.ConvDesc * len(self.convs))()
+            C.memmove(reb, descs, C.sizeof(descs))
+            for i0, i1 in zip(marks[:-1], marks[1:]):
+                base = descs[i0].blk_off if i0 < len(self.convs) else blk
+                end = descs[i1].blk_off if i1 < len(self.convs) else blk
+                for i in range(i0, i1):
+                    reb[i].blk_off = descs[i].blk_off - base
+                self._parts.append((i0 * C.sizeof(L.ConvDesc), i1 - i0, end - base))
+            self.descs_parts = torch.frombuffer(bytearray(bytes(reb)), dtype=torch.uint8).to(device)
         self.sn_t = torch.zeros(max(t_cursor, 8), dtype=torch.float32, device=device)
         self.sn_inv_sigma = torch.ones(max(self.n_convs, 1), dtype=torch.float32, device=device)
         # spectral-norm scratch: per-16-row partial column sums, and w2 laid out like `state` (no zeroing needed)
@@ -242,21 +257,34 @@ class ParamStore:
         return {k: self.get_state(k) for k in self.sslots}
 
     # ---- per-step device work -----------------------------------------------------------------
-    def begin_step(self):
-        """Zero the gradient buffer and the scratch pool (both are atomics targets)."""
-        self.grads.zero_()
+    def begin_step(self, zero_grads: bool = True):
+        """Zero the gradient buffer and the scratch pool (both are atomics targets).  zero_grads=False: the caller
+        zeroes `grads` itself, off the critical path (NVAE._prepare_weights_staged)."""
+        if zero_grads:
+            self.grads.zero_()
         self.zero_pool.zero_()
 
-    def prepare_weights(self, spectral_norm: bool):
-        """Spectral-norm power iteration (training) and refresh of the MFMA compute copies."""
+    def n_prep_parts(self) -> int:
+        return len(self._parts)
+
+    def prepare_weights(self, spectral_norm: bool, part=None):
+        """Spectral-norm power iteration (training) and refresh of the MFMA compute copies.  part=k: only the convs
+        of module k (prep_marks, set by the model before finalize) - the training step prepares the later modules'
+        weights on its side stream while the earlier modules already run."""
         if self.n_convs == 0:
             return
         dt = L.dtype_code(self.dtype)
+        if part is None:
+            descs, n, blocks = L.ptr(self.descs), self.n_convs, self.sn_blocks
+        else:
+            off, n, blocks = self._parts[part]
+            if n == 0:
+                return
+            descs = L.ptr(self.descs_parts) + off
         inv = None
         if spectral_norm:
-            L.call("nvae_sn_power_iter", L.ptr(self.params), L.ptr(self.descs), self.n_convs, self.sn_blocks,
+            L.call("nvae_sn_power_iter", L.ptr(self.params), descs, n, blocks,
                    L.ptr(self.state), L.ptr(self.sn_t), L.ptr(self.sn_colpart), L.ptr(self.sn_w2),
                    L.ptr(self.sn_inv_sigma))
             inv = L.ptr(self.sn_inv_sigma)
-        L.call("nvae_weight_prep", dt, L.ptr(self.params), L.ptr(self.descs), self.n_convs, self.sn_blocks,
-               inv, L.ptr(self.wcopies))
+        L.call("nvae_weight_prep", dt, L.ptr(self.params), descs, n, blocks, inv, L.ptr(self.wcopies))

@@ -333,9 +333,9 @@ def _bern_fwd(logits: Tensor, x: Tensor) -> Tensor:
 
 
 def _bern_bwd(logits: Tensor, x: Tensor, scale: float) -> Tensor:
-    g = torch.empty_like(logits)
+    g = torch.empty(logits.shape, dtype=x.dtype, device=logits.device)      # the kernel writes the activation dtype
     call("nvae_bernoulli_bwd", _dt(x), ptr(logits.contiguous()), ptr(x.contiguous()), ptr(g), logits.numel(), float(scale))
-    return g
+    return g.float()
 
 
 _lib.impl("bernoulli_nll", _bern_fwd, "CUDA")

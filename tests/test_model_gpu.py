@@ -4,8 +4,8 @@ parameter gradient, the Adamax update, BN moving statistics, spectral-norm state
 forward with IWAE terms, and ancestral sampling.
 
 Tolerances (stated per north_star): f32 path vs the fp64 oracle 1e-3 relative on losses and 5e-3 of
-the gradient scale per tensor; bf16 path 3e-2 on losses and 0.15 of the gradient scale (bf16 keeps
-8 significant bits through ~60 layers)."""
+the gradient scale per tensor; bf16 path 3e-2 on losses and 0.2 of the gradient scale for EVERY tensor (median
+below 5e-2; bf16 keeps 8 significant bits through ~60 layers), gradient cosine > 0.9993."""
 import math
 
 import pytest
@@ -52,7 +52,7 @@ def rel(a, b):
     return float((a - b).abs().max() / (b.abs().max() + 1e-12))
 
 
-@pytest.mark.parametrize("dtype,ltol,gtol", [(torch.float32, 1e-3, 5e-3), (torch.bfloat16, 3e-2, 0.4)],
+@pytest.mark.parametrize("dtype,ltol,gtol", [(torch.float32, 1e-3, 5e-3), (torch.bfloat16, 3e-2, 0.2)],
                          ids=["f32", "bf16"])
 def test_train_step_parity(lib, dev, dtype, ltol, gtol):
     orc, model, x, eps = build_pair(dev, dtype)
@@ -72,20 +72,21 @@ def test_train_step_parity(lib, dev, dtype, ltol, gtol):
         worst.append((rel(model.ps.get_grad(k), g_o), k))
     worst.sort(reverse=True)
     print("worst gradient errors:", worst[:8])
+    valid = sorted(e for e, k in worst if float(out_o["grads"][k].abs().max()) > 1e-6)
+    print(f"per-tensor gradient error over {len(valid)} tensors with a real gradient: median {valid[len(valid) // 2]:.2e} "
+          f"p90 {valid[len(valid) * 9 // 10]:.2e} p98 {valid[len(valid) * 98 // 100]:.2e} max {valid[-1]:.2e}")
     bad = [(e, k) for e, k in worst if e > gtol and float(out_o["grads"][k].abs().max()) > 1e-6]
-    if dtype == torch.float32:
-        assert not bad, bad[:10]
-    else:
-        # bf16 activations/gradients: a few reductions whose true value is a near-cancelling sum
-        # (e.g. a BN beta behind a 0.1-scaled SE branch) carry O(1) relative rounding noise; the
-        # f32 run of the same kernels is exact, so bound their NUMBER and check the direction below
-        assert len(bad) <= max(2, len(worst) // 50), bad[:10]
+    # bf16, measured over the 256 tensors with a real gradient: median 2.5e-2, 90th percentile 4.5e-2, 98th 6.6e-2,
+    # worst 0.11 of the tensor's scale (round 1 allowed 0.4 and exempted 2 % of the tensors)
+    assert not bad, bad[:10]
+    if dtype == torch.bfloat16:
+        assert valid[len(valid) // 2] < 5e-2 and valid[len(valid) * 9 // 10] < 9e-2
     # direction of the whole gradient
     go = torch.cat([out_o["grads"][k].reshape(-1) for k in out_o["grads"]])
     gp = torch.cat([model.ps.get_grad(k).double().cpu().reshape(-1) for k in out_o["grads"]])
     cos = float((go * gp).sum() / (go.norm() * gp.norm()))
     print("gradient cosine", cos)
-    assert cos > (0.99999 if dtype == torch.float32 else 0.995)
+    assert cos > (0.99999 if dtype == torch.float32 else 0.9993)      # bf16 measured: 0.99970-0.99974
     # Adamax update, BN moving statistics, spectral-norm state.  Adamax divides by max|g|, so an
     # element whose true gradient is 0 (e.g. a conv bias feeding a BatchNorm) moves by +-lr on
     # rounding noise alone in ANY f32 implementation: compare only elements with a real gradient.
@@ -380,11 +381,11 @@ def test_c2_architecture_parity(lib, dev, batch):
     print(f"C2 batch {batch}: gradient cosine {cos:.6f}, |g| {float(go.norm()):.3e}, per-tensor error median {med:.2e} "
           f"95th percentile {p95:.2e}, worst {errs[:4]}")
     if strict:
-        assert cos > 0.9995                        # (round 1: 0.99987; the chaos-free shrunken models reach > 0.99999)
-        assert med < 3e-2 and p95 < 0.2            # a wrong layer shows up as O(1) errors of its own tensors
+        assert cos > 0.9998                        # measured 0.999878 (0.99975 before the two-level f32 accumulation)
+        assert med < 2.5e-2 and p95 < 6e-2         # measured 1.5e-2 / 2.4e-2; a wrong layer shows up as O(1) errors
         # the few outliers are SE hidden units whose ReLU sits at its kink for one of the two images (a rounding
         # flips the unit: O(1) change of that row of w1 / b1) and biases feeding a BatchNorm (true gradient 0)
         assert sum(e > 0.25 for e, _ in errs) <= len(errs) // 100 and errs[0][0] < 2.0, errs[:12]
     else:
-        assert cos > 0.9                           # f32 PyTorch vs fp64 PyTorch: 0.9958 (see the docstring)
-        assert med < 0.5
+        assert cos > 0.993                         # measured 0.9971; f32 PyTorch vs fp64 PyTorch: 0.9958 (see the docstring)
+        assert med < 0.15                          # measured 6.6e-2
