@@ -196,10 +196,11 @@ def side_workload(args):
     from nvae_tf_amd import configs
     device = torch.device("cuda:0")
     torch.cuda.set_device(device)
-    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    dtype = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[args.dtype]
     c = configs.CONFIGS[args.workload]
     batch = args.batch if args.batch != BATCH_PER_GPU else c["batch"]
-    model = configs.build(args.workload, batch=batch, device=device, dtype=dtype)
+    model = configs.build(args.workload, batch=batch, device=device, dtype=dtype,
+                           loss_scale=None if args.loss_scale in (None, "dynamic") else float(args.loss_scale))
     H, W, Cc = c["input_hwc"]
     if Cc == 1:
         x = synthetic_batch(batch, 1, device)
@@ -238,7 +239,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=BATCH_PER_GPU, help="per-GPU batch")
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32"])
+    ap.add_argument("--loss-scale", type=str, default=None, help="f16: 'dynamic' (default) or a static factor")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--workload", default="mnist_c2", choices=["mnist_c2", "mnist_c1", "cifar10", "celeba64"],
@@ -255,7 +257,7 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback for the hot path)"
     device = torch.device(f"cuda:{local % max(torch.cuda.device_count(), 1)}")
     torch.cuda.set_device(device)
-    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    dtype = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[args.dtype]
     import torch.distributed as dist
 
     model = make_model(device, dtype, args.batch)
@@ -327,7 +329,7 @@ def main():
             "metric": "train_images_per_sec", "value": value, "unit": "images/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16" if dtype == torch.bfloat16 else "f32", "data": "synthetic",
+            "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": "MNIST 28x28 (zero-padded 32x32) NVAE paper defaults: groups [5,10], "
                                    "2 cells/group, 20 latents/group; full train step "
                                    "(SN + fwd + ELBO + bwd + Adamax)",

@@ -7,7 +7,7 @@
  *
  * Conventions
  *  - plain pointers and sizes only; all pointers are DEVICE pointers unless stated otherwise;
- *  - activations are NHWC, contiguous in C, element type `dtype` (NVAE_F32 / NVAE_BF16);
+ *  - activations are NHWC, contiguous in C, element type `dtype` (NVAE_F32 / NVAE_BF16 / NVAE_F16);
  *    statistics, losses, master weights, gradients of weights and optimizer slots are always f32;
  *  - every call enqueues on `stream` (a hipStream_t passed as void*) and never synchronises,
  *    allocates or frees, so a sequence of calls can be captured into a hipGraph;
@@ -30,6 +30,7 @@ extern "C" {
 
 #define NVAE_F32 0
 #define NVAE_BF16 1
+#define NVAE_F16 2      /* IEEE half activations, f32 accumulation / statistics / losses (BASELINE.json configs[4]) */
 
 #define NVAE_ACT_NONE 0
 #define NVAE_ACT_SWISH 1
@@ -41,7 +42,7 @@ extern "C" {
 
 /* Bumped whenever an entry point is added or a signature changes; the Python binding (nvae_tf_amd/_lib.py
  * ABI_VERSION) refuses to load a library that reports another value. */
-#define NVAE_ABI_VERSION 2
+#define NVAE_ABI_VERSION 3
 
 const char* nvae_last_error(void);
 int nvae_abi_version(void);
@@ -364,7 +365,7 @@ int nvae_sampler_bwd(int dtype, const float* enc_p, const float* dec_p, const fl
 int nvae_bernoulli_fwd(int dtype, const float* logits, const void* x, float* recon, int B, int H,
                        int W, int C, int crop, void* stream);
 int nvae_bernoulli_bwd(int dtype, const float* logits, const void* x, void* dlogits, long n,
-                       float inv_batch, void* stream);
+                       float inv_batch, const float* hyper /* NULL or loss scale source */, void* stream);
 
 /* ---- discretised mixture of logistics head (csrc/dmol.hip) ------------------------------------
  * NOT in the reference (train.py:219, README.md:25-27 list the CIFAR / CelebA heads as to-do); the
@@ -377,8 +378,8 @@ int nvae_bernoulli_bwd(int dtype, const float* logits, const void* x, void* dlog
  *           temperature divides the mixture logits and multiplies the logistic scale.           */
 int nvae_dmol_fwd(const float* logits, int ld, const float* x, float* nll, int B, int HW, int M,
                   void* stream);
-int nvae_dmol_bwd(int dtype, const float* logits, int ld, const float* x, void* dlogits, int B, int HW,
-                  int M, float scale, void* stream);
+int nvae_dmol_bwd(int dtype, const float* logits, int ld, const float* x, void* dlogits, int B,
+                  int HW, int M, float scale, const float* hyper /* NULL or loss scale source */, void* stream);
 int nvae_dmol_sample(const float* logits, int ld, const float* u_mix, const float* u_pix, float* out,
                      int B, int HW, int M, float temperature, void* stream);
 
@@ -386,6 +387,16 @@ int nvae_dmol_sample(const float* logits, int ld, const float* u_mix, const floa
 #define NVAE_HY_LR 0       /* lr / (1 - beta1^t)                       */
 #define NVAE_HY_BETA 1     /* KL warm-up coefficient (models.py:122)   */
 #define NVAE_HY_BALANCE 2  /* 1.0 if beta < 1 (models.py:123)          */
+/* loss scaling (f16 activations): the kernels that seed the backward pass (nvae_bernoulli_bwd, nvae_dmol_bwd,
+ * nvae_sampler_bwd, nvae_bn_absmax_bwd) multiply by hyper[NVAE_HY_LSCALE], nvae_adamax divides it out again through
+ * hyper[NVAE_HY_GSCALE] and skips the step when hyper[NVAE_HY_OVERFLOW] is set; nvae_grad_guard sets that flag when
+ * the gradient buffer holds a non-finite value and nvae_loss_scale_update adapts the scale (x 0.5 on overflow, x 2 after
+ * NVAE_LS_GROWTH_STEPS clean steps).  A zero in LSCALE / GSCALE means 1 (no scaling): the bf16 / f32 paths never set them. */
+#define NVAE_HY_GSCALE 3   /* 1 / loss scale                            */
+#define NVAE_HY_LSCALE 4   /* loss scale                                */
+#define NVAE_HY_GOOD 5     /* clean steps since the last scale change   */
+#define NVAE_HY_OVERFLOW 6 /* 1.0 = this step's gradient is non-finite  */
+#define NVAE_LS_GROWTH_STEPS 200
 #define NVAE_HY_SIZE 8
 #define NVAE_RES_LOSS 0
 #define NVAE_RES_BN 1
@@ -401,12 +412,17 @@ int nvae_loss_finalize(const float* kl_all, const float* am, const float* alphas
  * parameter buffer, C).                                                                         */
 int nvae_bn_absmax_fwd(const float* params, const int* table, int n_layers, float lambda,
                        float* bn_loss /*zeroed*/, int* argmax, void* stream);
+/* hyper: NULL, or the hyper buffer whose NVAE_HY_LSCALE multiplies the subgradient (loss scaling) */
 int nvae_bn_absmax_bwd(const float* params, float* grads, const int* table, const int* argmax,
-                       int n_layers, float lambda, void* stream);
+                       int n_layers, float lambda, const float* hyper, void* stream);
 
 /* ---- Adamax (train.py:131; Keras defaults) over a flat buffer ------------------------------ */
 int nvae_adamax(float* p, const float* g, float* m, float* u, long n, const float* hyper, float beta1,
                 float beta2, float eps, void* stream);
+/* dynamic loss scaling (f16 path; see the hyper layout): set hyper[NVAE_HY_OVERFLOW] if g[0..n) holds a non-finite
+ * value (before nvae_adamax), and adapt the scale afterwards.  Both are no-ops for the optimizer when never called. */
+int nvae_grad_guard(const float* g, long n, float* hyper, void* stream);
+int nvae_loss_scale_update(float* hyper, float min_scale, float max_scale, void* stream);
 
 /* ---- SpectralNormalization (TFA) power iteration + compute-copy preparation.
  *      One descriptor per wrapped conv; all offsets are element offsets into flat buffers.      */

@@ -13,11 +13,11 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libnvae_hip.so")
 
-ABI_VERSION = 2          # must equal nvae_abi_version() of the loaded library (include/nvae_hip.h NVAE_ABI_VERSION)
-F32, BF16 = 0, 1
+ABI_VERSION = 3          # must equal nvae_abi_version() of the loaded library (include/nvae_hip.h NVAE_ABI_VERSION)
+F32, BF16, F16 = 0, 1, 2
 ACT_NONE, ACT_SWISH, ACT_ELU = 0, 1, 2
 OP_AFFINE, OP_SWISH, OP_ELU = 0, 1, 2
-HY_LR, HY_BETA, HY_BALANCE, HY_SIZE = 0, 1, 2, 8
+HY_LR, HY_BETA, HY_BALANCE, HY_GSCALE, HY_LSCALE, HY_GOOD, HY_OVERFLOW, HY_SIZE = 0, 1, 2, 3, 4, 5, 6, 8
 RES_LOSS, RES_BN, RES_RECON, RES_KL, RES_SIZE = 0, 1, 2, 3, 8
 
 
@@ -117,15 +117,17 @@ _SIGS = {
     "nvae_sampler_fwd": [_i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i],
     "nvae_sampler_bwd": [_i, _p, _p, _p, _p, _p, _p, _f, _p, _p, _i, _i, _i],
     "nvae_bernoulli_fwd": [_i, _p, _p, _p, _i, _i, _i, _i, _i],
-    "nvae_bernoulli_bwd": [_i, _p, _p, _p, _l, _f],
+    "nvae_bernoulli_bwd": [_i, _p, _p, _p, _l, _f, _p],
     "nvae_dmol_fwd": [_p, _i, _p, _p, _i, _i, _i],
-    "nvae_dmol_bwd": [_i, _p, _i, _p, _p, _i, _i, _i, _f],
+    "nvae_dmol_bwd": [_i, _p, _i, _p, _p, _i, _i, _i, _f, _p],
     "nvae_dmol_sample": [_p, _i, _p, _p, _p, _i, _i, _i, _f],
     "nvae_kl_absmean": [_p, _i, _i, _p],
     "nvae_loss_finalize": [_p, _p, _p, _i, _i, _p, _p, _p, _p, _p, _p],
     "nvae_bn_absmax_fwd": [_p, _p, _i, _f, _p, _p],
-    "nvae_bn_absmax_bwd": [_p, _p, _p, _p, _i, _f],
+    "nvae_bn_absmax_bwd": [_p, _p, _p, _p, _i, _f, _p],
     "nvae_adamax": [_p, _p, _p, _p, _l, _p, _f, _f, _f],
+    "nvae_grad_guard": [_p, _l, _p],
+    "nvae_loss_scale_update": [_p, _f, _f],
     "nvae_sn_power_iter": [_p, _p, _i, _i, _p, _p, _p, _p, _p],
     "nvae_weight_prep": [_i, _p, _p, _i, _i, _p, _p],
 }
@@ -205,4 +207,6 @@ def dtype_code(dt: torch.dtype) -> int:
         return F32
     if dt == torch.bfloat16:
         return BF16
+    if dt == torch.float16:
+        return F16
     raise ValueError(f"unsupported activation dtype {dt}")

@@ -7,6 +7,8 @@
 #include "../../include/nvae_hip.h"
 
 typedef __bf16 bf16;
+typedef _Float16 f16;            // the third activation dtype (NVAE_F16): same kernels, v_mfma_f32_16x16x32_f16
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
@@ -31,6 +33,8 @@ extern thread_local char g_nvae_err[512];
     } while (0)
 
 static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+static inline bool is16(int dtype) { return dtype == NVAE_BF16 || dtype == NVAE_F16; }     // 16-bit activation types
+template <typename T> static constexpr int dtype_of() { return sizeof(T) == 4 ? NVAE_F32 : (__is_same(T, __bf16) ? NVAE_BF16 : NVAE_F16); }
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 // ---------------------------------------------------------------------------------------
@@ -71,12 +75,57 @@ template <> struct V8<bf16> {
     }
 };
 
+template <> struct V8<f16> {
+    static __device__ __forceinline__ void ld(const f16* p, float (&v)[8]) {
+        const f16x8 r = *(const f16x8*)p;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (float)r[j];          // v_cvt_f32_f16
+    }
+    static __device__ __forceinline__ void st(f16* p, const float (&v)[8]) {
+        f16x8 r;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r[j] = (f16)v[j];            // v_cvt_pk_f16_f32 pairs: RNE, saturating to inf
+        *(f16x8*)p = r;
+    }
+};
+
+// 16-B chunk of 8 sixteen-bit elements <-> 8 floats (the conv operand prologue works on raw uint4 chunks)
+template <typename T> __device__ __forceinline__ void unpack8(uint4 raw, float (&v)[8]);
+template <> __device__ __forceinline__ void unpack8<bf16>(uint4 raw, float (&v)[8]) {
+    v[0] = __uint_as_float(raw.x << 16); v[1] = __uint_as_float(raw.x & 0xffff0000u);
+    v[2] = __uint_as_float(raw.y << 16); v[3] = __uint_as_float(raw.y & 0xffff0000u);
+    v[4] = __uint_as_float(raw.z << 16); v[5] = __uint_as_float(raw.z & 0xffff0000u);
+    v[6] = __uint_as_float(raw.w << 16); v[7] = __uint_as_float(raw.w & 0xffff0000u);
+}
+template <> __device__ __forceinline__ void unpack8<f16>(uint4 raw, float (&v)[8]) {
+    const f16x8 r = __builtin_bit_cast(f16x8, raw);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = (float)r[j];
+}
+template <typename T> __device__ __forceinline__ uint4 pack8(const float (&v)[8]);
+template <> __device__ __forceinline__ uint4 pack8<bf16>(const float (&v)[8]) {
+    uint4 r;
+    r.x = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
+    r.y = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
+    r.z = (unsigned)f2bf(v[4]) | ((unsigned)f2bf(v[5]) << 16);
+    r.w = (unsigned)f2bf(v[6]) | ((unsigned)f2bf(v[7]) << 16);
+    return r;
+}
+template <> __device__ __forceinline__ uint4 pack8<f16>(const float (&v)[8]) {
+    f16x8 r;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] = (f16)v[j];
+    return __builtin_bit_cast(uint4, r);
+}
+
 template <typename T> __device__ __forceinline__ float ldf(const T* p);
 template <> __device__ __forceinline__ float ldf<float>(const float* p) { return *p; }
 template <> __device__ __forceinline__ float ldf<bf16>(const bf16* p) { return (float)*p; }
+template <> __device__ __forceinline__ float ldf<f16>(const f16* p) { return (float)*p; }
 template <typename T> __device__ __forceinline__ void stf(T* p, float v);
 template <> __device__ __forceinline__ void stf<float>(float* p, float v) { *p = v; }
 template <> __device__ __forceinline__ void stf<bf16>(bf16* p, float v) { *p = (bf16)v; }
+template <> __device__ __forceinline__ void stf<f16>(f16* p, float v) { *p = (f16)v; }
 
 // ---------------------------------------------------------------------------------------
 // math
@@ -128,6 +177,13 @@ __device__ __forceinline__ unsigned fdiv(unsigned n, const FastDiv& f) {
     return (unsigned)(((unsigned long long)n * f.M) >> 40);
 }
 
+// loss scale of the backward seeds (include/nvae_hip.h, hyper layout): 0 or no buffer = 1
+__device__ __forceinline__ float loss_scale_of(const float* hyper) {
+    if (!hyper) return 1.f;
+    const float s = hyper[NVAE_HY_LSCALE];
+    return s != 0.f ? s : 1.f;
+}
+
 // Activation codes shared with the host
 #define ACT_NONE 0
 #define ACT_SWISH 1
@@ -136,4 +192,5 @@ __device__ __forceinline__ unsigned fdiv(unsigned n, const FastDiv& f) {
 #define DISPATCH_T(dtype, ...)                                        \
     if ((dtype) == NVAE_F32) { typedef float T; __VA_ARGS__ }         \
     else if ((dtype) == NVAE_BF16) { typedef bf16 T; __VA_ARGS__ }    \
+    else if ((dtype) == NVAE_F16) { typedef f16 T; __VA_ARGS__ }      \
     else NVAE_FAIL(NVAE_EINVAL, "bad dtype %d", (int)(dtype));

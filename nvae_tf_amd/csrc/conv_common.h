@@ -4,6 +4,7 @@
 
 template <typename T> struct Tr;
 template <> struct Tr<bf16> { static constexpr int VE = 8; };
+template <> struct Tr<f16> { static constexpr int VE = 8; };
 template <> struct Tr<float> { static constexpr int VE = 4; };
 
 // bijective XCD remap (cdna guide T1): consecutive logical tiles land on one XCD
@@ -12,11 +13,19 @@ __device__ __forceinline__ int xcd_remap(int id, int n) {
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + l;
 }
 
+// one 16x16x32 MFMA on two raw 16-B operand chunks of 16-bit type T (bf16 or f16)
+template <typename T>
+__device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 acc) {
+    if constexpr (sizeof(T) == 2 && !__is_same(T, bf16))
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), acc, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc, 0, 0, 0);
+}
+
 template <typename T>
 __device__ __forceinline__ void mfma_step(const uint4& a, const uint4& b, f32x4& acc) {
     if constexpr (sizeof(T) == 2) {
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a),
-                                                      __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
+        acc = mfma16<T>(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc);
     } else {
         // the lane's 16-B chunk holds 4 consecutive k; A and B use the same k permutation
         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.x), __uint_as_float(b.x), acc, 0, 0, 0);

@@ -319,10 +319,11 @@ __global__ __launch_bounds__(256) void k_conv_smallk_wgrad(const T* __restrict__
 #pragma unroll 8
         for (int r = 0; r < RT; ++r) {
             float d[4];
-            if (sizeof(T) == 2) {
+            if constexpr (sizeof(T) == 2) {
                 const uint2 u = *(const uint2*)(&sd[r][n4 * 4]);
-                d[0] = __uint_as_float(u.x << 16); d[1] = __uint_as_float(u.x & 0xffff0000u);
-                d[2] = __uint_as_float(u.y << 16); d[3] = __uint_as_float(u.y & 0xffff0000u);
+                float d8[8];
+                unpack8<T>(make_uint4(u.x, u.y, 0u, 0u), d8);
+                d[0] = d8[0]; d[1] = d8[1]; d[2] = d8[2]; d[3] = d8[3];
             } else {
                 const float4 u = *(const float4*)(&sd[r][n4 * 4]);
                 d[0] = u.x; d[1] = u.y; d[2] = u.z; d[3] = u.w;

@@ -53,38 +53,30 @@ struct ConvPre {
     void* act_out; int act_ld;
 };
 
-template <typename T> __device__ __forceinline__ uint4 pre_chunk(uint4 raw, const float* sc, const float* sh, int act);
-template <> __device__ __forceinline__ uint4 pre_chunk<bf16>(uint4 raw, const float* sc, const float* sh, int act) {
-    float v[8];
-    v[0] = __uint_as_float(raw.x << 16); v[1] = __uint_as_float(raw.x & 0xffff0000u);
-    v[2] = __uint_as_float(raw.y << 16); v[3] = __uint_as_float(raw.y & 0xffff0000u);
-    v[4] = __uint_as_float(raw.z << 16); v[5] = __uint_as_float(raw.z & 0xffff0000u);
-    v[6] = __uint_as_float(raw.w << 16); v[7] = __uint_as_float(raw.w & 0xffff0000u);
-    const float4 s0 = *(const float4*)sc, s1 = *(const float4*)(sc + 4), h0 = *(const float4*)sh, h1 = *(const float4*)(sh + 4);
-    const float scv[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
-    const float shv[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+template <typename T> __device__ __forceinline__ uint4 pre_chunk(uint4 raw, const float* sc, const float* sh, int act) {
+    if constexpr (sizeof(T) == 2) {
+        float v[8];
+        unpack8<T>(raw, v);
+        const float4 s0 = *(const float4*)sc, s1 = *(const float4*)(sc + 4), h0 = *(const float4*)sh, h1 = *(const float4*)(sh + 4);
+        const float scv[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+        const float shv[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const float p = v[j] * scv[j] + shv[j];
-        v[j] = act == ACT_SWISH ? swishf_(p) : p;
-    }
-    uint4 r;
-    r.x = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
-    r.y = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
-    r.z = (unsigned)f2bf(v[4]) | ((unsigned)f2bf(v[5]) << 16);
-    r.w = (unsigned)f2bf(v[6]) | ((unsigned)f2bf(v[7]) << 16);
-    return r;
-}
-template <> __device__ __forceinline__ uint4 pre_chunk<float>(uint4 raw, const float* sc, const float* sh, int act) {
-    float v[4] = {__uint_as_float(raw.x), __uint_as_float(raw.y), __uint_as_float(raw.z), __uint_as_float(raw.w)};
-    const float4 s0 = *(const float4*)sc, h0 = *(const float4*)sh;
-    const float scv[4] = {s0.x, s0.y, s0.z, s0.w}, shv[4] = {h0.x, h0.y, h0.z, h0.w};
+        for (int j = 0; j < 8; ++j) {
+            const float p = v[j] * scv[j] + shv[j];
+            v[j] = act == ACT_SWISH ? swishf_(p) : p;
+        }
+        return pack8<T>(v);
+    } else {
+        float v[4] = {__uint_as_float(raw.x), __uint_as_float(raw.y), __uint_as_float(raw.z), __uint_as_float(raw.w)};
+        const float4 s0 = *(const float4*)sc, h0 = *(const float4*)sh;
+        const float scv[4] = {s0.x, s0.y, s0.z, s0.w}, shv[4] = {h0.x, h0.y, h0.z, h0.w};
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const float p = v[j] * scv[j] + shv[j];
-        v[j] = act == ACT_SWISH ? swishf_(p) : p;
+        for (int j = 0; j < 4; ++j) {
+            const float p = v[j] * scv[j] + shv[j];
+            v[j] = act == ACT_SWISH ? swishf_(p) : p;
+        }
+        return make_uint4(__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3]));
     }
-    return make_uint4(__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3]));
 }
 
 template <typename T, int BM, int BN, int WM, int WN, bool BNBWD, typename RowMap>
@@ -789,7 +781,7 @@ __global__ __launch_bounds__(WM * 128) void k_conv_halo(
 #endif
 // halo kernel eligibility (must agree between the launcher and nvae_conv_gemm_stats_rows)
 static bool conv_halo_ok(int dtype, const NvaeConvGeom* g) {
-    const int cch = dtype == NVAE_BF16 ? 64 : 32;
+    const int cch = is16(dtype) ? 64 : 32;
     const int N = g->Cout;
     const long w192 = (long)cdiv(N, 192) * 192, w128 = (long)cdiv(N, 128) * 128;
     return g->KH == g->KW && (g->KH == 5 || g->KH == 3) && g->stride == 1 && g->div == 1 &&
@@ -846,7 +838,7 @@ static int launch_conv_gemm(const NvaeConvGeom* g, const void* src, const void* 
     BnFinArgs sfin{};
     if (stats_fin) sfin = *stats_fin;
     const bool use_pre = pre.on;
-    be.m_tiles = cdiv((long)g->B * g->Hout * g->Wout, conv_gemm_bm(sizeof(T) == 2 ? NVAE_BF16 : NVAE_F32, g));
+    be.m_tiles = cdiv((long)g->B * g->Hout * g->Wout, conv_gemm_bm(dtype_of<T>(), g));
     be.rows = cdiv(be.m_tiles, 64);
     const int M = g->B * g->Hout * g->Wout, K = g->KH * g->KW * g->Cin, N = g->Cout;
     FastDiv fd_hw = make_fastdiv((unsigned)(g->Hout * g->Wout)), fd_w = make_fastdiv((unsigned)g->Wout);
@@ -856,7 +848,7 @@ static int launch_conv_gemm(const NvaeConvGeom* g, const void* src, const void* 
     const int vec_epi = (g->out_ld % vo == 0) && aligned16(out) &&
                         (!residual || (g->res_ld % (int)(16 / sizeof(T)) == 0 && aligned16(residual)));
     if (be.x && (!vec_epi || out_f32 || N % 8 != 0)) return 1;     // fusion needs the vector epilogue
-    if (conv_halo_ok(sizeof(T) == 2 ? NVAE_BF16 : NVAE_F32, g)) {
+    if (conv_halo_ok(dtype_of<T>(), g)) {
         const int pw = g->Win / 16, ppi = (g->Hin / 16) * pw;
         const int mt = g->B * ppi, nt = cdiv(N, 192);
         if (use_pre && g->Cin > PRE_MAXC_HALO) return 2;
@@ -907,7 +899,7 @@ extern "C" int nvae_conv_gemm(int dtype, const NvaeConvGeom* g, const void* src,
                               float* stats, void* stream) {
     if (int e = check_geom_mfma("conv_gemm", g)) return e;
     NVAE_REQUIRE(src && wT && out, "conv_gemm: NULL pointer");
-    const int ve = (dtype == NVAE_BF16) ? 8 : 4;
+    const int ve = is16(dtype) ? 8 : 4;
     NVAE_REQUIRE(g->Cin % ve == 0 && g->in_ld % ve == 0 && w_ld % ve == 0,
                  "conv_gemm: Cin=%d in_ld=%d w_ld=%d must be multiples of %d (use nvae_conv_direct)", g->Cin, g->in_ld, w_ld, ve);
     NVAE_REQUIRE(w_ld >= g->KH * g->KW * g->Cin, "conv_gemm: w_ld too small");
@@ -927,7 +919,7 @@ extern "C" int nvae_conv_gemm_ex(int dtype, const NvaeConvGeom* g, const void* s
                                  const NvaeConvPre* pre, const NvaeBnFin* fin, void* stream) {
     if (int e = check_geom_mfma("conv_gemm_ex", g)) return e;
     NVAE_REQUIRE(src && wT && out, "conv_gemm_ex: NULL pointer");
-    const int ve = (dtype == NVAE_BF16) ? 8 : 4;
+    const int ve = is16(dtype) ? 8 : 4;
     NVAE_REQUIRE(g->Cin % ve == 0 && g->in_ld % ve == 0 && w_ld % ve == 0,
                  "conv_gemm_ex: Cin=%d in_ld=%d w_ld=%d must be multiples of %d (use nvae_conv_direct)", g->Cin, g->in_ld, w_ld, ve);
     NVAE_REQUIRE(w_ld >= g->KH * g->KW * g->Cin, "conv_gemm_ex: w_ld too small");
@@ -982,7 +974,7 @@ extern "C" int nvae_conv_gemm_bnbwd(int dtype, const NvaeConvGeom* g, const void
                                     const NvaeBnBwdFuse* f, void* stream) {
     if (int e = check_geom_mfma("conv_gemm_bnbwd", g)) return e;
     NVAE_REQUIRE(src && wT && out && f, "conv_gemm_bnbwd: NULL pointer");
-    const int ve = (dtype == NVAE_BF16) ? 8 : 4;
+    const int ve = is16(dtype) ? 8 : 4;
     NVAE_REQUIRE(g->Cin % ve == 0 && g->in_ld % ve == 0 && w_ld % ve == 0,
                  "conv_gemm_bnbwd: Cin=%d in_ld=%d w_ld=%d must be multiples of %d", g->Cin, g->in_ld, w_ld, ve);
     NVAE_REQUIRE(w_ld >= g->KH * g->KW * g->Cin, "conv_gemm_bnbwd: w_ld too small");

@@ -138,10 +138,10 @@ __global__ __launch_bounds__(WK* WN * 64) void k_conv_wgrad2(
             for (int j = 0; j < BCH; ++j) {
                 uint4 v = *(const uint4*)(bufB + (tid + NT * j) * 16);
                 if constexpr (sizeof(T) == 2) {
-                    bsum[0] += __uint_as_float(v.x << 16); bsum[1] += __uint_as_float(v.x & 0xffff0000u);
-                    bsum[2] += __uint_as_float(v.y << 16); bsum[3] += __uint_as_float(v.y & 0xffff0000u);
-                    bsum[4] += __uint_as_float(v.z << 16); bsum[5] += __uint_as_float(v.z & 0xffff0000u);
-                    bsum[6] += __uint_as_float(v.w << 16); bsum[7] += __uint_as_float(v.w & 0xffff0000u);
+                    float u8[8];
+                    unpack8<T>(v, u8);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) bsum[e] += u8[e];
                 } else {
                     bsum[0] += __uint_as_float(v.x); bsum[1] += __uint_as_float(v.y);
                     bsum[2] += __uint_as_float(v.z); bsum[3] += __uint_as_float(v.w);
@@ -180,7 +180,7 @@ __global__ __launch_bounds__(WK* WN * 64) void k_conv_wgrad2(
                 for (int i = 0; i < MI; ++i)
 #pragma unroll
                     for (int j = 0; j < NI; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = mfma16<T>(af[i], bfr[j], acc[i][j]);
             }
         } else {
 #pragma unroll
@@ -286,9 +286,9 @@ __global__ void k_slab_reduce(const float* __restrict__ slab, int S, int K, int 
 __device__ __forceinline__ int seg_s8(int m) { return (m & 3) | (((m >> 3) & 1) << 2); }
 __device__ __forceinline__ int seg_s4(int m) { return ((m >> 1) & 1) | (((m >> 3) & 1) << 1); }
 
-template <int KS>
-__global__ __launch_bounds__(512) void k_wgrad_halo(NvaeConvGeom g, const bf16* __restrict__ x,
-                                                    const bf16* __restrict__ dy, float* dw, int dw_ld,
+template <typename T, int KS>
+__global__ __launch_bounds__(512) void k_wgrad_halo(NvaeConvGeom g, const T* __restrict__ x,
+                                                    const T* __restrict__ dy, float* dw, int dw_ld,
                                                     int n_tiles, int cchunks, int hp_per_split,
                                                     int hp_w /*W/16*/, int hp_per_img /*(H/8)*(W/16)*/,
                                                     int hp_total, const uint4* __restrict__ zeros) {
@@ -427,7 +427,7 @@ __global__ __launch_bounds__(512) void k_wgrad_halo(NvaeConvGeom g, const bf16* 
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
                     for (int j = 0; j < 3; ++j)
-                        acc[kw][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[kw][i][j], 0, 0, 0);
+                        acc[kw][i][j] = mfma16<T>(af[i], bfr[j], acc[kw][i][j]);
             }
         }
     }
@@ -449,12 +449,13 @@ __global__ __launch_bounds__(512) void k_wgrad_halo(NvaeConvGeom g, const bf16* 
 }
 
 static bool wgrad_halo_ok(int dtype, const NvaeConvGeom* g, const float* db) {
-    return dtype == NVAE_BF16 && db == nullptr && g->KH == g->KW && (g->KH == 5 || g->KH == 3) && g->stride == 1 &&
+    return is16(dtype) && db == nullptr && g->KH == g->KW && (g->KH == 5 || g->KH == 3) && g->stride == 1 &&
            g->div == 1 && g->pad_t == (g->KH - 1) / 2 && g->pad_l == (g->KW - 1) / 2 && g->Hin == g->Hout &&
            g->Win == g->Wout && g->Hin % 8 == 0 && g->Win % 16 == 0 && g->Cin % 64 == 0 && g->Cout % 192 == 0 &&
            (long)g->B * g->Hin * g->Win >= 16384;
 }
 
+template <typename T>
 static void launch_wgrad_halo(const NvaeConvGeom* g, const void* x, const void* dy, float* dw, int dw_ld,
                               hipStream_t s) {
     const int n_tiles = g->Cout / 192, cchunks = g->Cin / 64, KS = g->KH;
@@ -468,10 +469,10 @@ static void launch_wgrad_halo(const NvaeConvGeom* g, const void* x, const void* 
     dim3 grid(tiles, nsplit);
     const uint4* zeros = zero_page();
     if (KS == 5)
-        hipLaunchKernelGGL((k_wgrad_halo<5>), grid, 512, 0, s, *g, (const bf16*)x, (const bf16*)dy, dw, dw_ld, n_tiles,
+        hipLaunchKernelGGL((k_wgrad_halo<T, 5>), grid, 512, 0, s, *g, (const T*)x, (const T*)dy, dw, dw_ld, n_tiles,
                            cchunks, hps, hp_w, hp_per_img, hp_total, zeros);
     else
-        hipLaunchKernelGGL((k_wgrad_halo<3>), grid, 512, 0, s, *g, (const bf16*)x, (const bf16*)dy, dw, dw_ld, n_tiles,
+        hipLaunchKernelGGL((k_wgrad_halo<T, 3>), grid, 512, 0, s, *g, (const T*)x, (const T*)dy, dw, dw_ld, n_tiles,
                            cchunks, hps, hp_w, hp_per_img, hp_total, zeros);
 }
 
@@ -548,14 +549,14 @@ static int launch_conv_wgrad(const NvaeConvGeom* g, int n, const void* const* x,
 extern "C" long nvae_conv_wgrad_scratch_n(int dtype, const NvaeConvGeom* g, int n_layers) {
     if (!g) return 0;
     const long K = (long)g->KH * g->KW * g->Cin, N = g->Cout;
-    WgradPlan p = dtype == NVAE_BF16 ? plan_conv_wgrad<bf16>(g, 1L << 60, n_layers) : plan_conv_wgrad<float>(g, 1L << 60, n_layers);
+    WgradPlan p = is16(dtype) ? plan_conv_wgrad<bf16>(g, 1L << 60, n_layers) : plan_conv_wgrad<float>(g, 1L << 60, n_layers);
     return p.slab ? (long)p.nsplit * (K + 1) * N : 0;
 }
 extern "C" long nvae_conv_wgrad_scratch(int dtype, const NvaeConvGeom* g) { return nvae_conv_wgrad_scratch_n(dtype, g, 1); }
 
 static int check_wgrad_args(const char* who, int dtype, const NvaeConvGeom* g, int dw_ld) {
     if (int e = check_geom_mfma(who, g)) return e;
-    const int ve = (dtype == NVAE_BF16) ? 8 : 4;
+    const int ve = is16(dtype) ? 8 : 4;
     NVAE_REQUIRE(dw_ld >= g->Cout, "%s: dw_ld too small", who);
     NVAE_REQUIRE(g->Cin % ve == 0 && g->in_ld % ve == 0 && g->Cout % ve == 0 && g->out_ld % ve == 0,
                  "%s: Cin=%d Cout=%d and their lds must be multiples of %d (use nvae_conv_direct_wgrad)", who, g->Cin, g->Cout, ve);
@@ -568,7 +569,8 @@ extern "C" int nvae_conv_wgrad(int dtype, const NvaeConvGeom* g, const void* x, 
     NVAE_REQUIRE(x && dy && dw, "conv_wgrad: bad args");
     NVAE_REQUIRE(aligned16(x) && aligned16(dy), "conv_wgrad: x/dy must be 16-B aligned");
     if (wgrad_halo_ok(dtype, g, db)) {
-        launch_wgrad_halo(g, x, dy, dw, dw_ld, (hipStream_t)stream);
+        if (dtype == NVAE_BF16) launch_wgrad_halo<bf16>(g, x, dy, dw, dw_ld, (hipStream_t)stream);
+        else launch_wgrad_halo<f16>(g, x, dy, dw, dw_ld, (hipStream_t)stream);
         NVAE_LAUNCH_CHECK("wgrad_halo");
         return NVAE_OK;
     }
@@ -590,7 +592,10 @@ extern "C" int nvae_conv_wgrad_batched(int dtype, const NvaeConvGeom* g, int n, 
         NVAE_REQUIRE(!db || db[i], "conv_wgrad_batched: db must be given for all layers or none");
     }
     if (wgrad_halo_ok(dtype, g, db ? db[0] : nullptr)) {
-        for (int i = 0; i < n; ++i) launch_wgrad_halo(g, x[i], dy[i], dw[i], dw_ld, (hipStream_t)stream);
+        for (int i = 0; i < n; ++i) {
+            if (dtype == NVAE_BF16) launch_wgrad_halo<bf16>(g, x[i], dy[i], dw[i], dw_ld, (hipStream_t)stream);
+            else launch_wgrad_halo<f16>(g, x[i], dy[i], dw[i], dw_ld, (hipStream_t)stream);
+        }
         NVAE_LAUNCH_CHECK("wgrad_halo");
         return NVAE_OK;
     }

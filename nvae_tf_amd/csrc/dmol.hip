@@ -128,7 +128,8 @@ extern "C" int nvae_dmol_fwd(const float* logits, int ld, const float* x, float*
 template <typename T>
 __global__ __launch_bounds__(256) void k_dmol_bwd(const float* __restrict__ logits, int ld,
                                                   const float* __restrict__ x, T* __restrict__ dl,
-                                                  long npix, int M, float scale) {
+                                                  long npix, int M, float scale, const float* __restrict__ hyper) {
+    scale *= loss_scale_of(hyper);
     for (long pix = blockIdx.x * 256L + threadIdx.x; pix < npix; pix += gridDim.x * 256L) {
         const float* l = logits + pix * ld;
         T* d = dl + pix * ld;
@@ -155,13 +156,13 @@ __global__ __launch_bounds__(256) void k_dmol_bwd(const float* __restrict__ logi
 }
 
 extern "C" int nvae_dmol_bwd(int dtype, const float* logits, int ld, const float* x, void* dlogits, int B,
-                             int HW, int M, float scale, void* stream) {
+                             int HW, int M, float scale, const float* hyper, void* stream) {
     NVAE_REQUIRE(B > 0 && HW > 0 && logits && x && dlogits, "dmol_bwd: bad args");
     NVAE_REQUIRE(M >= 1 && M <= DMOL_MAXM && ld >= 10 * M, "dmol_bwd: M=%d must be in [1, %d] and ld=%d >= 10*M", M, DMOL_MAXM, ld);
     const long npix = (long)B * HW;
     long g = (npix + 255) / 256;
     if (g > 4096) g = 4096;
-    DISPATCH_T(dtype, hipLaunchKernelGGL((k_dmol_bwd<T>), (int)g, 256, 0, (hipStream_t)stream, logits, ld, x, (T*)dlogits, npix, M, scale);)
+    DISPATCH_T(dtype, hipLaunchKernelGGL((k_dmol_bwd<T>), (int)g, 256, 0, (hipStream_t)stream, logits, ld, x, (T*)dlogits, npix, M, scale, hyper);)
     NVAE_LAUNCH_CHECK("dmol_bwd");
     return NVAE_OK;
 }

@@ -35,6 +35,20 @@ template <> struct DwVec<bf16> {
         *(uint2*)p = u;
     }
 };
+template <> struct DwVec<f16> {
+    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+    static __device__ __forceinline__ void ld(const f16* p, float (&v)[4]) {
+        const h4 u = *(const h4*)p;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = (float)u[j];
+    }
+    static __device__ __forceinline__ void st(f16* p, const float (&v)[4]) {
+        h4 u;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) u[j] = (f16)v[j];
+        *(h4*)p = u;
+    }
+};
 template <> struct DwVec<float> {
     static __device__ __forceinline__ void ld(const float* p, float (&v)[4]) {
         const float4 u = *(const float4*)p;
@@ -137,15 +151,30 @@ __global__ __launch_bounds__(256) void k_dw5_fwd(const T* __restrict__ x, const 
 // 25 x 2 taps + 16 accumulators fit in ~100 VGPRs, so four workgroups share a CU and hide each other's
 // LDS latency.  The FMAs compile to v_pk_fma_f32 on the channel pair.
 typedef float dw_f2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ dw_f2 dw_unpack(unsigned v) {      // bf16 pair -> f32 pair
+template <typename T> __device__ __forceinline__ dw_f2 dw_unpack(unsigned v);      // 16-bit pair -> f32 pair
+template <> __device__ __forceinline__ dw_f2 dw_unpack<bf16>(unsigned v) {
     dw_f2 r;
     r.x = __uint_as_float(v << 16); r.y = __uint_as_float(v & 0xffff0000u);
     return r;
 }
+template <> __device__ __forceinline__ dw_f2 dw_unpack<f16>(unsigned v) {
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    const h2 h = __builtin_bit_cast(h2, v);
+    dw_f2 r;
+    r.x = (float)h[0]; r.y = (float)h[1];
+    return r;
+}
+template <typename T> __device__ __forceinline__ unsigned dw_pack(dw_f2 v);
+template <> __device__ __forceinline__ unsigned dw_pack<bf16>(dw_f2 v) { return (unsigned)f2bf(v.x) | ((unsigned)f2bf(v.y) << 16); }
+template <> __device__ __forceinline__ unsigned dw_pack<f16>(dw_f2 v) {
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    h2 h; h[0] = (f16)v.x; h[1] = (f16)v.y;
+    return __builtin_bit_cast(unsigned, h);
+}
 
-template <int TH, int TW, int IMGS>
-__global__ __launch_bounds__(256, 2) void k_dw5_fwd_ring(const bf16* __restrict__ x, const float* __restrict__ w,
-                                                      const float* __restrict__ bias, bf16* y, int B, int H,
+template <typename T, int TH, int TW, int IMGS>
+__global__ __launch_bounds__(256, 2) void k_dw5_fwd_ring(const T* __restrict__ x, const float* __restrict__ w,
+                                                      const float* __restrict__ bias, T* y, int B, int H,
                                                       int W, int C, int tiles_x, int tiles_per_img, int flip,
                                                       int acc, const uint4* __restrict__ zeros,
                                                       float* __restrict__ stats) {
@@ -212,7 +241,7 @@ __global__ __launch_bounds__(256, 2) void k_dw5_fwd_ring(const bf16* __restrict_
         long b; int ty, tx;
         unit_of(i, b, ty, tx);
         b += img;
-        const bf16* sx = (const bf16*)(lds + (i % NS) * STAGE) + (long)img * HTH * HTW * DW_CC;
+        const T* sx = (const T*)(lds + (i % NS) * STAGE) + (long)img * HTH * HTW * DW_CC;
         const int gy0 = ty * TH + rb * 2, gx0 = tx * TW + cb * 4;
         const bool live = cval && b < B;
         dw_f2 o[2][4];
@@ -222,14 +251,14 @@ __global__ __launch_bounds__(256, 2) void k_dw5_fwd_ring(const bf16* __restrict_
             for (int p = 0; p < 4; ++p) {
                 o[r][p] = bv;
                 if (acc && live && gy0 + r < H && gx0 + p < W)
-                    o[r][p] = dw_unpack(*(const unsigned*)(y + (((b * H + gy0 + r) * (long)W + gx0 + p) * C + c)));
+                    o[r][p] = dw_unpack<T>(*(const unsigned*)(y + (((b * H + gy0 + r) * (long)W + gx0 + p) * C + c)));
             }
 #pragma unroll
         for (int hr = 0; hr < 6; ++hr) {             // halo row rb*2 + hr feeds output rows hr-4 .. hr
             dw_f2 xr[8];
 #pragma unroll
             for (int q = 0; q < 8; ++q)
-                xr[q] = dw_unpack(*(const unsigned*)(sx + ((rb * 2 + hr) * HTW + cb * 4 + q) * DW_CC + cp * 2));
+                xr[q] = dw_unpack<T>(*(const unsigned*)(sx + ((rb * 2 + hr) * HTW + cb * 4 + q) * DW_CC + cp * 2));
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
                 const int kh = hr - r;
@@ -248,7 +277,7 @@ __global__ __launch_bounds__(256, 2) void k_dw5_fwd_ring(const bf16* __restrict_
                 for (int p = 0; p < 4; ++p)
                     if (gy0 + r < H && gx0 + p < W) {
                         *(unsigned*)(y + (((b * H + gy0 + r) * (long)W + gx0 + p) * C + c)) =
-                            (unsigned)f2bf(o[r][p].x) | ((unsigned)f2bf(o[r][p].y) << 16);
+                            dw_pack<T>(o[r][p]);
                         st1 += o[r][p];
                         st2 += o[r][p] * o[r][p];
                     }
@@ -292,7 +321,7 @@ static long dw_ring_rows(int B, int H, int W, int C) {
 }
 
 extern "C" int nvae_dwconv5_stats_rows(int dtype, int B, int H, int W, int C) {
-    if (dtype != NVAE_BF16 || B <= 0 || H <= 0 || W <= 0 || C < 8 || C % 8) return 0;
+    if (!is16(dtype) || B <= 0 || H <= 0 || W <= 0 || C < 8 || C % 8) return 0;
     return cdiv(dw_ring_rows(B, H, W, C), 64);
 }
 
@@ -300,17 +329,20 @@ static int dwconv5_impl(int dtype, const void* x, const float* w, const float* b
                         int C, int flip, int accumulate, float* stats, void* stream) {
     NVAE_REQUIRE(B > 0 && H > 0 && W > 0 && C >= 8 && C % 8 == 0, "dwconv5: bad shape");
     NVAE_REQUIRE(aligned16(x) && aligned16(y) && aligned16(w) && (!bias || aligned16(bias)), "dwconv5: alignment");
-    NVAE_REQUIRE(!stats || (dtype == NVAE_BF16 && !flip && !accumulate), "dwconv5: statistics only from the bf16 forward");
+    NVAE_REQUIRE(!stats || (is16(dtype) && !flip && !accumulate), "dwconv5: statistics only from the 16-bit forward");
     const int strips = cdiv(C, DW_CC);
     NVAE_REQUIRE(B <= 65535, "dwconv5: batch too large for the grid");
-    if (dtype == NVAE_BF16) {
+    if (is16(dtype)) {
         const bool small = H <= 4 && W <= 4;
         const int tx = small ? 1 : cdiv(W, 8), ty = small ? 1 : cdiv(H, 8);
         dim3 grid(strips, (unsigned)dw_ring_rows(B, H, W, C));
-        if (small)
-            hipLaunchKernelGGL((k_dw5_fwd_ring<4, 4, 4>), grid, 256, 0, (hipStream_t)stream, (const bf16*)x, w, bias, (bf16*)y, B, H, W, C, tx, tx * ty, flip, accumulate, zero_page(), stats);
-        else
-            hipLaunchKernelGGL((k_dw5_fwd_ring<8, 8, 1>), grid, 256, 0, (hipStream_t)stream, (const bf16*)x, w, bias, (bf16*)y, B, H, W, C, tx, tx * ty, flip, accumulate, zero_page(), stats);
+#define DW_RING(T_)                                                                                              \
+        if (small)                                                                                               \
+            hipLaunchKernelGGL((k_dw5_fwd_ring<T_, 4, 4, 4>), grid, 256, 0, (hipStream_t)stream, (const T_*)x, w, bias, (T_*)y, B, H, W, C, tx, tx * ty, flip, accumulate, zero_page(), stats); \
+        else                                                                                                     \
+            hipLaunchKernelGGL((k_dw5_fwd_ring<T_, 8, 8, 1>), grid, 256, 0, (hipStream_t)stream, (const T_*)x, w, bias, (T_*)y, B, H, W, C, tx, tx * ty, flip, accumulate, zero_page(), stats);
+        if (dtype == NVAE_BF16) { DW_RING(bf16) } else { DW_RING(f16) }
+#undef DW_RING
         NVAE_LAUNCH_CHECK("dwconv5");
         return NVAE_OK;
     }
@@ -441,8 +473,8 @@ __global__ __launch_bounds__(256) void k_dw5_wgrad(const T* __restrict__ x, cons
 // ring and thread layout as k_dw5_fwd_ring (channel pair x 2x4 block of dy pixels): per unit 48 reads
 // of the x halo + 8 of dy feed 200 packed FMAs into the thread's 25 tap-pair accumulators, which live in
 // registers across all the units the workgroup visits.
-template <int TH, int TW, int IMGS>
-__global__ __launch_bounds__(256, 2) void k_dw5_wgrad_ring(const bf16* __restrict__ x, const bf16* __restrict__ dy,
+template <typename T, int TH, int TW, int IMGS>
+__global__ __launch_bounds__(256, 2) void k_dw5_wgrad_ring(const T* __restrict__ x, const T* __restrict__ dy,
                                                            float* dw, float* db, int B, int H, int W, int C,
                                                            int tiles_x, int tiles_per_img,
                                                            const uint4* __restrict__ zeros) {
@@ -506,14 +538,14 @@ __global__ __launch_bounds__(256, 2) void k_dw5_wgrad_ring(const bf16* __restric
         wait_vmcnt<0>();
         __syncthreads();
         if (i + 1 < nmine) issue(i + 1);
-        const bf16* sx = (const bf16*)(lds + (i % NS) * STAGE) + (long)img * HTH * HTW * DW_CC;
-        const bf16* sd = (const bf16*)(lds + (i % NS) * STAGE) + KX * 256 * 8 + (long)img * TH * TW * DW_CC;
+        const T* sx = (const T*)(lds + (i % NS) * STAGE) + (long)img * HTH * HTW * DW_CC;
+        const T* sd = (const T*)(lds + (i % NS) * STAGE) + KX * 256 * 8 + (long)img * TH * TW * DW_CC;
         dw_f2 g[2][4];
 #pragma unroll
         for (int r = 0; r < 2; ++r)
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
-                g[r][p] = dw_unpack(*(const unsigned*)(sd + ((rb * 2 + r) * TW + cb * 4 + p) * DW_CC + cp * 2));
+                g[r][p] = dw_unpack<T>(*(const unsigned*)(sd + ((rb * 2 + r) * TW + cb * 4 + p) * DW_CC + cp * 2));
                 ab += g[r][p];
             }
 #pragma unroll
@@ -521,7 +553,7 @@ __global__ __launch_bounds__(256, 2) void k_dw5_wgrad_ring(const bf16* __restric
             dw_f2 xr[8];
 #pragma unroll
             for (int q = 0; q < 8; ++q)
-                xr[q] = dw_unpack(*(const unsigned*)(sx + ((rb * 2 + hr) * HTW + cb * 4 + q) * DW_CC + cp * 2));
+                xr[q] = dw_unpack<T>(*(const unsigned*)(sx + ((rb * 2 + hr) * HTW + cb * 4 + q) * DW_CC + cp * 2));
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
                 const int kh = hr - r;
@@ -581,19 +613,25 @@ extern "C" int nvae_dwconv5_wgrad(int dtype, const void* x, const void* dy, floa
     const long chunks = (units + upb - 1) / upb;
     NVAE_REQUIRE(chunks <= 65535, "dwconv5_wgrad: too many tiles");
     dim3 grid(strips, (unsigned)chunks);
-    if (dtype == NVAE_BF16 && !small) {
-        hipLaunchKernelGGL((k_dw5_wgrad_ring<8, 8, 1>), grid, 256, 0, (hipStream_t)stream, (const bf16*)x, (const bf16*)dy, dw, db, B, H, W, C, tx, tx * ty, zero_page());
+    if (is16(dtype) && !small) {
+        if (dtype == NVAE_BF16)
+            hipLaunchKernelGGL((k_dw5_wgrad_ring<bf16, 8, 8, 1>), grid, 256, 0, (hipStream_t)stream, (const bf16*)x, (const bf16*)dy, dw, db, B, H, W, C, tx, tx * ty, zero_page());
+        else
+            hipLaunchKernelGGL((k_dw5_wgrad_ring<f16, 8, 8, 1>), grid, 256, 0, (hipStream_t)stream, (const f16*)x, (const f16*)dy, dw, db, B, H, W, C, tx, tx * ty, zero_page());
         NVAE_LAUNCH_CHECK("dwconv5_wgrad");
         return NVAE_OK;
     }
-    if (dtype == NVAE_BF16) {            // 4x4 tower: units of four images
+    if (is16(dtype)) {            // 4x4 tower: units of four images
         const long u4 = (B + 3) / 4;
         long w4 = u4 / 4;
         if (w4 > 1024 / strips) w4 = 1024 / strips;
         if (w4 < cdiv(256, strips)) w4 = cdiv(256, strips);
         if (w4 > u4) w4 = u4;
         if (w4 < 1) w4 = 1;
-        hipLaunchKernelGGL((k_dw5_wgrad_ring<4, 4, 4>), dim3(strips, (unsigned)w4), 256, 0, (hipStream_t)stream, (const bf16*)x, (const bf16*)dy, dw, db, B, H, W, C, 1, 1, zero_page());
+        if (dtype == NVAE_BF16)
+            hipLaunchKernelGGL((k_dw5_wgrad_ring<bf16, 4, 4, 4>), dim3(strips, (unsigned)w4), 256, 0, (hipStream_t)stream, (const bf16*)x, (const bf16*)dy, dw, db, B, H, W, C, 1, 1, zero_page());
+        else
+            hipLaunchKernelGGL((k_dw5_wgrad_ring<f16, 4, 4, 4>), dim3(strips, (unsigned)w4), 256, 0, (hipStream_t)stream, (const f16*)x, (const f16*)dy, dw, db, B, H, W, C, 1, 1, zero_page());
         NVAE_LAUNCH_CHECK("dwconv5_wgrad");
         return NVAE_OK;
     }

@@ -141,20 +141,55 @@ __global__ void k_advance_counter(unsigned long long* counter, unsigned long lon
 __global__ void k_adamax(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                          float* __restrict__ u, long n4, const float* __restrict__ hyper, float b1,
                          float b2, float eps) {
+    if (hyper[NVAE_HY_OVERFLOW] != 0.f) return;       // non-finite gradient (nvae_grad_guard): skip the step
     const float lr_t = hyper[NVAE_HY_LR];
+    const float gs = hyper[NVAE_HY_GSCALE] != 0.f ? hyper[NVAE_HY_GSCALE] : 1.f;     // undo the loss scale (f16 path)
     for (long i = blockIdx.x * 256L + threadIdx.x; i < n4; i += gridDim.x * 256L) {
         float4 pv = ((float4*)p)[i], gv = ((const float4*)g)[i], mv = ((float4*)m)[i], uv = ((float4*)u)[i];
         float* pp = (float*)&pv; float* gp = (float*)&gv; float* mp = (float*)&mv; float* up = (float*)&uv;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            mp[j] = b1 * mp[j] + (1.f - b1) * gp[j];
-            up[j] = fmaxf(b2 * up[j], fabsf(gp[j]));
+            const float g1 = gp[j] * gs;
+            mp[j] = b1 * mp[j] + (1.f - b1) * g1;
+            up[j] = fmaxf(b2 * up[j], fabsf(g1));
             pp[j] -= lr_t * mp[j] / (up[j] + eps);
         }
         ((float4*)p)[i] = pv; ((float4*)m)[i] = mv; ((float4*)u)[i] = uv;
     }
 }
 
+
+// ---- dynamic loss scaling (f16 activations) ------------------------------------------------------------------
+// Any non-finite element of the (all-reduced) gradient sets the overflow flag; the store is idempotent, so the race
+// between workgroups is benign.
+__global__ void k_grad_guard(const float* __restrict__ g, long n4, float* hyper) {
+    bool bad = false;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n4; i += gridDim.x * 256L) {
+        const uint4 v = ((const uint4*)g)[i];
+        bad |= ((v.x & 0x7f800000u) == 0x7f800000u) | ((v.y & 0x7f800000u) == 0x7f800000u) |
+               ((v.z & 0x7f800000u) == 0x7f800000u) | ((v.w & 0x7f800000u) == 0x7f800000u);
+    }
+    if (__any(bad) && (threadIdx.x & 63) == 0) hyper[NVAE_HY_OVERFLOW] = 1.0f;
+}
+__global__ void k_loss_scale_update(float* hyper, float min_scale, float max_scale) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    float s = hyper[NVAE_HY_LSCALE] != 0.f ? hyper[NVAE_HY_LSCALE] : 1.f, good = hyper[NVAE_HY_GOOD];
+    if (hyper[NVAE_HY_OVERFLOW] != 0.f) { s = fmaxf(s * 0.5f, min_scale); good = 0.f; }
+    else if (++good >= (float)NVAE_LS_GROWTH_STEPS) { s = fminf(s * 2.0f, max_scale); good = 0.f; }
+    hyper[NVAE_HY_LSCALE] = s; hyper[NVAE_HY_GSCALE] = 1.0f / s; hyper[NVAE_HY_GOOD] = good; hyper[NVAE_HY_OVERFLOW] = 0.f;
+}
+extern "C" int nvae_grad_guard(const float* g, long n, float* hyper, void* stream) {
+    NVAE_REQUIRE(n > 0 && n % 4 == 0 && g && hyper && aligned16(g), "grad_guard: bad args");
+    hipLaunchKernelGGL(k_grad_guard, ew_grid(n / 4), 256, 0, (hipStream_t)stream, g, n / 4, hyper);
+    NVAE_LAUNCH_CHECK("grad_guard");
+    return NVAE_OK;
+}
+extern "C" int nvae_loss_scale_update(float* hyper, float min_scale, float max_scale, void* stream) {
+    NVAE_REQUIRE(hyper && min_scale > 0.f && max_scale >= min_scale, "loss_scale_update: bad args");
+    hipLaunchKernelGGL(k_loss_scale_update, 1, 64, 0, (hipStream_t)stream, hyper, min_scale, max_scale);
+    NVAE_LAUNCH_CHECK("loss_scale_update");
+    return NVAE_OK;
+}
 
 extern "C" int nvae_unary_fwd(int dtype, int op, const void* x, void* y, long n, float a, float b,
                               void* stream) {
@@ -203,6 +238,9 @@ extern "C" int nvae_cast(int sd, int dd, const void* src, void* dst, long n, voi
     else if (sd == NVAE_BF16 && dd == NVAE_F32) hipLaunchKernelGGL((k_cast<bf16, float>), ew_grid(n8), 256, 0, s, (const bf16*)src, (float*)dst, n8);
     else if (sd == NVAE_F32 && dd == NVAE_F32) hipLaunchKernelGGL((k_cast<float, float>), ew_grid(n8), 256, 0, s, (const float*)src, (float*)dst, n8);
     else if (sd == NVAE_BF16 && dd == NVAE_BF16) hipLaunchKernelGGL((k_cast<bf16, bf16>), ew_grid(n8), 256, 0, s, (const bf16*)src, (bf16*)dst, n8);
+    else if (sd == NVAE_F32 && dd == NVAE_F16) hipLaunchKernelGGL((k_cast<float, f16>), ew_grid(n8), 256, 0, s, (const float*)src, (f16*)dst, n8);
+    else if (sd == NVAE_F16 && dd == NVAE_F32) hipLaunchKernelGGL((k_cast<f16, float>), ew_grid(n8), 256, 0, s, (const f16*)src, (float*)dst, n8);
+    else if (sd == NVAE_F16 && dd == NVAE_F16) hipLaunchKernelGGL((k_cast<f16, f16>), ew_grid(n8), 256, 0, s, (const f16*)src, (f16*)dst, n8);
     else NVAE_FAIL(NVAE_EINVAL, "cast: bad dtypes %d->%d", sd, dd);
     NVAE_LAUNCH_CHECK("cast");
     return NVAE_OK;

@@ -78,6 +78,7 @@ __global__ void k_sampler_bwd(const float* __restrict__ enc_p, const float* __re
                               const float* __restrict__ coeff, const float* __restrict__ hyper,
                               float inv_batch, T* __restrict__ d_enc, T* __restrict__ d_dec, int L,
                               long n) {
+    inv_batch *= loss_scale_of(hyper);
     const float ckl = hyper[NVAE_HY_BETA] * coeff[0] * inv_batch;
     for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += gridDim.x * 256L) {
         long pix = i / L;
@@ -155,17 +156,18 @@ extern "C" int nvae_bernoulli_fwd(int dtype, const float* logits, const void* x,
 
 template <typename T>
 __global__ void k_bernoulli_bwd(const float* __restrict__ logits, const T* __restrict__ x,
-                                T* __restrict__ dl, long n, float inv_batch) {
+                                T* __restrict__ dl, long n, float inv_batch, const float* __restrict__ hyper) {
+    inv_batch *= loss_scale_of(hyper);
     for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += gridDim.x * 256L)
         stf<T>(dl + i, (sigmoidf_(logits[i]) - ldf<T>(x + i)) * inv_batch);
 }
 
 extern "C" int nvae_bernoulli_bwd(int dtype, const float* logits, const void* x, void* dlogits, long n,
-                                  float inv_batch, void* stream) {
+                                  float inv_batch, const float* hyper, void* stream) {
     NVAE_REQUIRE(n > 0 && logits && x && dlogits, "bernoulli_bwd: bad args");
     long g = (n + 255) / 256;
     if (g > 2048) g = 2048;
-    DISPATCH_T(dtype, hipLaunchKernelGGL((k_bernoulli_bwd<T>), (int)g, 256, 0, (hipStream_t)stream, logits, (const T*)x, (T*)dlogits, n, inv_batch);)
+    DISPATCH_T(dtype, hipLaunchKernelGGL((k_bernoulli_bwd<T>), (int)g, 256, 0, (hipStream_t)stream, logits, (const T*)x, (T*)dlogits, n, inv_batch, hyper);)
     NVAE_LAUNCH_CHECK("bernoulli_bwd");
     return NVAE_OK;
 }
@@ -281,18 +283,19 @@ extern "C" int nvae_bn_absmax_fwd(const float* params, const int* table, int n_l
 
 __global__ void k_bn_absmax_bwd(const float* __restrict__ params, float* grads,
                                 const int* __restrict__ table, const int* __restrict__ argmax,
-                                int n_layers, float lambda) {
+                                int n_layers, float lambda, const float* __restrict__ hyper) {
     int layer = blockIdx.x * 256 + threadIdx.x;
     if (layer >= n_layers) return;
+    lambda *= loss_scale_of(hyper);
     int idx = table[2 * layer] + argmax[layer];
     float v = params[idx];
     grads[idx] += lambda * (v > 0.f ? 1.f : (v < 0.f ? -1.f : 0.f));
 }
 
 extern "C" int nvae_bn_absmax_bwd(const float* params, float* grads, const int* table,
-                                  const int* argmax, int n_layers, float lambda, void* stream) {
+                                  const int* argmax, int n_layers, float lambda, const float* hyper, void* stream) {
     NVAE_REQUIRE(n_layers > 0 && params && grads && table && argmax, "bn_absmax_bwd: bad args");
-    hipLaunchKernelGGL(k_bn_absmax_bwd, cdiv(n_layers, 256), 256, 0, (hipStream_t)stream, params, grads, table, argmax, n_layers, lambda);
+    hipLaunchKernelGGL(k_bn_absmax_bwd, cdiv(n_layers, 256), 256, 0, (hipStream_t)stream, params, grads, table, argmax, n_layers, lambda, hyper);
     NVAE_LAUNCH_CHECK("bn_absmax_bwd");
     return NVAE_OK;
 }

@@ -144,6 +144,15 @@ template <> struct Pack16<bf16> {
         V8<bf16>::st(p + 8, b);
     }
 };
+template <> struct Pack16<f16> {
+    static __device__ __forceinline__ void store(f16* p, const float (&v)[16]) {
+        float a[8], b[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { a[j] = v[j]; b[j] = v[8 + j]; }
+        V8<f16>::st(p, a);
+        V8<f16>::st(p + 8, b);
+    }
+};
 template <> struct Pack16<float> {
     static __device__ __forceinline__ void store(float* p, const float (&v)[16]) {
 #pragma unroll

@@ -26,7 +26,10 @@ from .preprocess import Preprocess
 ADAMAX_B1, ADAMAX_B2, ADAMAX_EPS = 0.9, 0.999, 1e-7   # Keras Adamax defaults [3P], train.py:131
 # single-GPU overlap of the step's HBM-bound bookkeeping with its launch-bound compute (both default on):
 OVERLAP_PREP = os.environ.get("NVAE_OVERLAP_PREP", "1") != "0"      # SN + weight copies of later modules on the side stream
-OVERLAP_ADAMAX = os.environ.get("NVAE_OVERLAP_ADAMAX", "1") != "0"  # Adamax of a finished backward segment on the side stream
+# Adamax of a finished backward segment on the side stream: measured SLOWER (21.1-21.3 vs 20.4 ms/step) - cutting the
+# backward pass into segments flushes the weight-gradient queue five times, and smaller same-shape batches cost more
+# than the 0.3 ms of Adamax that gets hidden (the NVAE_WGRAD_FLUSH sweep shows the same: 32 -> 22.0, 256 -> 20.7 ms)
+OVERLAP_ADAMAX = os.environ.get("NVAE_OVERLAP_ADAMAX", "0") != "0"
 
 
 class NVAE:
@@ -35,13 +38,24 @@ class NVAE:
                  n_postprocess_blocks, n_post_process_cells, sr_lambda, scale_factor, total_epochs,
                  n_total_iterations, step_based_warmup, input_shape, *, device="cuda:0",
                  dtype=torch.bfloat16, seed=1, lr_decay_steps: Optional[int] = None, base_lr=1e-3,
-                 head: Optional[str] = None, num_mixture_dec: int = 10):
+                 head: Optional[str] = None, num_mixture_dec: int = 10, loss_scale=None):
         """Positional arguments as models.py:17-36.  input_shape = [B, H, W, C] (B ignored).
+        dtype: activation type of the kernels - torch.bfloat16 (default), torch.float16 or torch.float32; master
+        weights, statistics, KL / losses and optimizer state are f32 in every case.  loss_scale: factor on the
+        backward seeds (dL/dlogits, dL/dKL, the BN regulariser), undone inside Adamax, for float16 activations, whose
+        gradients have 5 exponent bits.  A float = static scale; "dynamic" (the default for float16) = device-side
+        dynamic scaling: a step whose gradient holds a non-finite value is skipped and halves the scale, 200 clean
+        steps double it (nvae_grad_guard / nvae_loss_scale_update; no host round trip, so it lives inside the
+        captured graphs).  None = 1.0 for bf16 / f32.
         head: "bernoulli" (the reference's binary-MNIST likelihood, default for C == 1) or "dmol"
         (discretised mixture of `num_mixture_dec` logistics over RGB, default for C == 3; the
         reference leaves it unimplemented)."""
         assert len(n_groups_per_scale) == n_latent_scales
         self.sr_lambda = sr_lambda
+        if loss_scale is None:
+            loss_scale = "dynamic" if dtype == torch.float16 else 1.0
+        self.dynamic_loss_scale = loss_scale == "dynamic"
+        self.loss_scale = 2.0 ** -8 if self.dynamic_loss_scale else float(loss_scale)     # (initial value if dynamic)
         self.n_latent_per_group = n_latent_per_group
         self.n_latent_scales = n_latent_scales
         self.n_groups_per_scale = [int(g) for g in n_groups_per_scale]
@@ -103,6 +117,7 @@ class NVAE:
         self._segments = []          # [(tape_lo, tape_hi, grad_lo, grad_hi)] in backward order, set by _forward
         dev = self.device
         self.hyper = torch.zeros(L.HY_SIZE, dtype=torch.float32, device=dev)
+        self.hyper[L.HY_LSCALE], self.hyper[L.HY_GSCALE] = self.loss_scale, 1.0 / self.loss_scale
         self.results = torch.zeros(L.RES_SIZE, dtype=torch.float32, device=dev)
         self.alphas = self.calculate_kl_alphas(n_latent_scales, self.n_groups_per_scale).to(dev)
         self.coeff = torch.ones(self.n_groups, dtype=torch.float32, device=dev)
@@ -303,8 +318,9 @@ class NVAE:
         t = self.opt_iterations + 1
         lr_t = self.learning_rate(self.opt_iterations) / (1 - ADAMAX_B1 ** t)
         h = torch.zeros(L.HY_SIZE, dtype=torch.float32)
+        h = h[:3]                    # (slots 3.. hold the loss-scale state, maintained on the device)
         h[L.HY_LR], h[L.HY_BETA], h[L.HY_BALANCE] = lr_t, beta, 1.0 if beta < 1 else 0.0
-        self.hyper.copy_(h, non_blocking=False)
+        self.hyper[:3].copy_(h, non_blocking=False)
 
     def _seg_forward(self, x: torch.Tensor, eps_list, spectral_norm=True):
         """SN + forward + per-rank loss statistics.  Returns the context holding the tape."""
@@ -323,9 +339,9 @@ class NVAE:
                    L.ptr(self._bn_loss), L.ptr(ps.bn_argmax))
         logits = self._forward(ctx, x, eps_list)
         if self.head == "dmol":
-            ops.dmol_nll(ctx, logits, x, buf["recon"], 1.0 / B, self.num_mixture_dec)
+            ops.dmol_nll(ctx, logits, x, buf["recon"], 1.0 / B, self.num_mixture_dec, hyper=self.hyper)
         else:
-            ops.bernoulli_nll(ctx, logits, x, buf["recon"], 1.0 / B)
+            ops.bernoulli_nll(ctx, logits, x, buf["recon"], 1.0 / B, hyper=self.hyper)
         L.call("nvae_kl_absmean", L.ptr(buf["kl_all"]), self.n_groups, B, L.ptr(self.am))
         self._logits = logits
         return ctx
@@ -375,7 +391,7 @@ class NVAE:
             nb = len(ps.bn_loss_layers)
             if nb:      # subgradient of the BN regulariser: depends on the parameters only, so it goes first
                 L.call("nvae_bn_absmax_bwd", L.ptr(ps.params), L.ptr(ps.grads), L.ptr(ps.bn_table),
-                       L.ptr(ps.bn_argmax), nb, float(self.sr_lambda))
+                       L.ptr(ps.bn_argmax), nb, float(self.sr_lambda), L.ptr(self.hyper))
         if part is None:
             ctx.backward()
         else:
@@ -401,15 +417,21 @@ class NVAE:
     def _seg_update(self, lo: int = 0, hi: Optional[int] = None):
         ps = self.ps
         hi = ps.params.numel() if hi is None else hi
+        whole = lo == 0 and hi == ps.params.numel()
+        if self.dynamic_loss_scale and whole:      # a non-finite gradient anywhere -> Adamax skips the step
+            L.call("nvae_grad_guard", L.ptr(ps.grads), ps.grads.numel(), L.ptr(self.hyper))
         if hi > lo:
             L.call("nvae_adamax", L.ptr(ps.params) + 4 * lo, L.ptr(ps.grads) + 4 * lo, L.ptr(ps.adam_m) + 4 * lo,
                    L.ptr(ps.adam_u) + 4 * lo, hi - lo, L.ptr(self.hyper), ADAMAX_B1, ADAMAX_B2, ADAMAX_EPS)
+        if self.dynamic_loss_scale and whole:
+            L.call("nvae_loss_scale_update", L.ptr(self.hyper), 2.0 ** -24, 2.0 ** 16)
 
     def _fused_update(self) -> bool:
         """Single GPU: no collective stands between a backward segment and its optimizer step, so the Adamax launch
         of a finished segment's parameter range goes onto the side stream behind that segment's weight gradients
         and runs under the next segment's data-gradient chain (0.3 ms of HBM-bound work per step at C2)."""
-        return OVERLAP_ADAMAX and self.reducer is None and self.overlap_wgrad and self._side is not None
+        return (OVERLAP_ADAMAX and self.reducer is None and self.overlap_wgrad and self._side is not None
+                and not self.dynamic_loss_scale)
 
     def _backward_with_update(self, ctx: Ctx, B: int):
         for part in range(self.n_segments()):
@@ -473,7 +495,7 @@ class NVAE:
         self._static_x = torch.zeros(tuple(batch_shape), device=self.device,
                                      dtype=torch.float32 if self.head == "dmol" else self.dtype)
         ps = self.ps
-        snap = [(t, t.clone()) for t in (ps.params, ps.state, ps.adam_m, ps.adam_u, self.rng_counter,
+        snap = [(t, t.clone()) for t in (ps.params, ps.state, ps.adam_m, ps.adam_u, self.rng_counter, self.hyper,
                                          self.coeff, self.am, self.results)]
         self._set_hyper()
         side = torch.cuda.Stream(device=self.device)

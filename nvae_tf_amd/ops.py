@@ -88,7 +88,7 @@ class Ctx:
         self.flush_every = int(os.environ.get("NVAE_WGRAD_FLUSH", "256"))
         self.dtype = dtype
         self.dt = L.dtype_code(dtype)
-        self.ve = 8 if dtype == torch.bfloat16 else 4
+        self.ve = 4 if dtype == torch.float32 else 8
         self.training = training
         self.record = record
         self.tape: List[Callable[[], None]] = []
@@ -782,8 +782,9 @@ def sampler(ctx: Ctx, enc_p: Var, dec_p: Optional[Var], eps: torch.Tensor, kl_ou
 
 
 def bernoulli_nll(ctx: Ctx, logits: Var, x: torch.Tensor, recon_out: torch.Tensor, inv_batch: float,
-                  crop: bool = False):
-    """calculate_recon_loss, models.py:242-250."""
+                  crop: bool = False, hyper: Optional[torch.Tensor] = None):
+    """calculate_recon_loss, models.py:242-250.  hyper: the step's hyper buffer (its loss scale multiplies the
+    backward seed), or None."""
     B, H, W, Cc = logits.t.shape
     assert logits.t.dtype == torch.float32
     call("nvae_bernoulli_fwd", ctx.dt, ptr(logits.t), ptr(x), ptr(recon_out), B, H, W, Cc, int(crop))
@@ -791,11 +792,12 @@ def bernoulli_nll(ctx: Ctx, logits: Var, x: torch.Tensor, recon_out: torch.Tenso
         def bwd():
             logits.g = ctx.empty(logits.t.shape)
             call("nvae_bernoulli_bwd", ctx.dt, ptr(logits.t), ptr(x), ptr(logits.g), logits.t.numel(),
-                 inv_batch)
+                 inv_batch, ptr(hyper))
         ctx.tape.append(bwd)
 
 
-def dmol_nll(ctx: Ctx, logits: Var, x32: torch.Tensor, recon_out: torch.Tensor, inv_batch: float, n_mix: int):
+def dmol_nll(ctx: Ctx, logits: Var, x32: torch.Tensor, recon_out: torch.Tensor, inv_batch: float, n_mix: int,
+             hyper: Optional[torch.Tensor] = None):
     """-log p(x) under the discretised mixture of logistics (oracle dmol_log_prob); x32 f32 in [0, 1]."""
     B, H, W, ld = logits.t.shape
     assert logits.t.dtype == torch.float32 and x32.dtype == torch.float32 and x32.shape == (B, H, W, 3)
@@ -803,7 +805,8 @@ def dmol_nll(ctx: Ctx, logits: Var, x32: torch.Tensor, recon_out: torch.Tensor, 
     if ctx.record:
         def bwd():
             logits.g = ctx.empty(logits.t.shape)
-            call("nvae_dmol_bwd", ctx.dt, ptr(logits.t), ld, ptr(x32), ptr(logits.g), B, H * W, n_mix, inv_batch)
+            call("nvae_dmol_bwd", ctx.dt, ptr(logits.t), ld, ptr(x32), ptr(logits.g), B, H * W, n_mix, inv_batch,
+                 ptr(hyper))
         ctx.tape.append(bwd)
 
 

@@ -159,7 +159,7 @@ class ParamStore:
         self.zero_pool = torch.zeros(zero_pool_floats, dtype=torch.float32, device=device)
         self.zero_reserved = 0
         # ---- compute copies + descriptors for spectral norm / weight prep
-        ve = 8 if dtype == torch.bfloat16 else 4
+        ve = 4 if dtype == torch.float32 else 8
         cursor = t_cursor = blk = p_cursor = 0
         descs = (L.ConvDesc * len(self.convs))()
         for i, c in enumerate(self.convs):

@@ -14,7 +14,7 @@ loop, `torch.compile` graphs (fake impls) and `torch.library.opcheck`:
                     skip_scale, branch_scale)                                               (common.py:127-142)
   nvae::bernoulli_nll(logits, x)                 per-image -log p(x | logits)               (models.py:242-250)
 
-All tensors are NHWC on the GPU, activations bf16 or f32, parameters f32.  No CPU implementation is registered: on a
+All tensors are NHWC on the GPU, activations bf16, f16 or f32, parameters f32.  No CPU implementation is registered: on a
 CPU tensor the dispatcher raises, like every other entry into this package."""
 from __future__ import annotations
 
@@ -45,7 +45,9 @@ def _dt(t: Tensor) -> int:
         return L.BF16
     if t.dtype == torch.float32:
         return L.F32
-    raise TypeError(f"nvae ops take bf16 or f32 activations, got {t.dtype}")
+    if t.dtype == torch.float16:
+        return L.F16
+    raise TypeError(f"nvae ops take bf16, f16 or f32 activations, got {t.dtype}")
 
 
 def _check_nhwc(x: Tensor, name: str):
@@ -334,7 +336,7 @@ def _bern_fwd(logits: Tensor, x: Tensor) -> Tensor:
 
 def _bern_bwd(logits: Tensor, x: Tensor, scale: float) -> Tensor:
     g = torch.empty(logits.shape, dtype=x.dtype, device=logits.device)      # the kernel writes the activation dtype
-    call("nvae_bernoulli_bwd", _dt(x), ptr(logits.contiguous()), ptr(x.contiguous()), ptr(g), logits.numel(), float(scale))
+    call("nvae_bernoulli_bwd", _dt(x), ptr(logits.contiguous()), ptr(x.contiguous()), ptr(g), logits.numel(), float(scale), None)
     return g.float()
 
 

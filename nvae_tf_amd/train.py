@@ -25,7 +25,7 @@ def save_checkpoint(model, path, epoch):
     ps = model.ps
     torch.save({"params": ps.params.cpu(), "state": ps.state.cpu(), "adam_m": ps.adam_m.cpu(),
                 "adam_u": ps.adam_u.cpu(), "steps": model.steps, "opt_iterations": model.opt_iterations,
-                "epoch": epoch, "rng_counter": model.rng_counter.cpu()}, path)
+                "epoch": epoch, "rng_counter": model.rng_counter.cpu(), "hyper": model.hyper.cpu()}, path)
 
 
 def load_checkpoint(model, path):
@@ -35,6 +35,8 @@ def load_checkpoint(model, path):
     ps.adam_m.copy_(ck["adam_m"]); ps.adam_u.copy_(ck["adam_u"])
     model.steps, model.opt_iterations = int(ck["steps"]), int(ck["opt_iterations"])
     model.rng_counter.copy_(ck["rng_counter"])
+    if "hyper" in ck:                         # the loss-scale state of the f16 path lives in hyper[3:]
+        model.hyper.copy_(ck["hyper"])
     return int(ck["epoch"])
 
 
@@ -151,7 +153,9 @@ def main(args):
                  n_total_iterations=batches_per_epoch * args.epochs, step_based_warmup=args.step_based_warmup,
                  input_shape=[args.batch_size // world] + hwc, device=f"cuda:{local}",
                  num_mixture_dec=args.num_mixture_dec,
-                 dtype=torch.bfloat16 if args.dtype == "bf16" else torch.float32, seed=args.seed + rank,
+                 dtype={"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[args.dtype],
+                 loss_scale=(None if args.loss_scale is None else args.loss_scale if args.loss_scale == "dynamic"
+                             else float(args.loss_scale)), seed=args.seed + rank,
                  lr_decay_steps=args.epochs * batches_per_epoch)
     model.tf_literal = args.tf_literal
     if world > 1:
@@ -208,7 +212,10 @@ def parse_args(argv=None):
     p.add_argument("--multiprocessing", action="store_true")
     p.add_argument("--seed", type=int, default=1)
     # additions of this build
-    p.add_argument("--dtype", choices=["bf16", "f32"], default="bf16", help="compute dtype of the HIP path")
+    p.add_argument("--dtype", choices=["bf16", "f16", "f32"], default="bf16", help="activation dtype of the HIP path")
+    p.add_argument("--loss_scale", type=str, default=None,
+                   help="f16 activations: 'dynamic' (default for f16: skip + halve on overflow, double after 200 clean "
+                        "steps, on the device) or a static factor; undone inside Adamax")
     p.add_argument("--data_dir", type=str, default=None, help="directory with mnist.npz or the IDX files")
     p.add_argument("--synthetic", action="store_true", help="random MNIST-shaped data (no files needed)")
     p.add_argument("--no_graph", action="store_true", help="launch eagerly instead of replaying hipGraphs")

@@ -45,7 +45,7 @@ def test_dmol_nll_and_gradient(lib, dev, M, ld):
     assert float(((nll.cpu().double() - nll_ref).abs() / nll_ref.abs()).max()) < 1e-5
     for dt, code, tol in ((torch.float32, 0, 2e-4), (torch.bfloat16, 1, 6e-3)):
         dl = torch.full((B, H, W, ld), 7.0, dtype=dt, device=dev)
-        call("nvae_dmol_bwd", code, ptr(lp), ld, ptr(x32), ptr(dl), B, H * W, M, 0.25)
+        call("nvae_dmol_bwd", code, ptr(lp), ld, ptr(x32), ptr(dl), B, H * W, M, 0.25, None)
         got = dl.double().cpu()
         assert float(got[..., 10 * M:].abs().max()) == 0.0 if ld > 10 * M else True
         err = float((got[..., :10 * M] - g_ref).abs().max() / g_ref.abs().max())

@@ -1,6 +1,7 @@
 """GPU parity tests of the individual kernels, called through the C ABI (ctypes), against fp64
 PyTorch-CPU references of the same op.  Tolerances: f32 kernels 2e-4 relative to the output scale
-(f32 MFMA is an exact fmaf chain, the slack covers summation order); bf16 kernels 2e-2."""
+(f32 MFMA is an exact fmaf chain, the slack covers summation order); bf16 kernels 2e-2; f16 kernels (11 significant
+bits, the BASELINE.json configs[4] dtype) 3e-3."""
 import ctypes as C
 import math
 
@@ -10,8 +11,8 @@ import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 
-TOL = {torch.float32: 2e-4, torch.bfloat16: 2.5e-2}
-DTYPES = [torch.float32, torch.bfloat16]
+TOL = {torch.float32: 2e-4, torch.bfloat16: 2.5e-2, torch.float16: 3e-3}
+DTYPES = [torch.float32, torch.bfloat16, torch.float16]
 
 
 def rel_err(a, b):
@@ -72,7 +73,7 @@ CONV_CASES = [
 ]
 
 
-@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16", "f16"])
 @pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: "k{k}_ci{cin}_co{cout}_s{stride}_u{up}_H{H}".format(**c))
 def test_conv_fwd_bwd(lib, dev, dtype, case):
     from nvae_tf_amd import ops
@@ -128,7 +129,7 @@ def test_conv_fwd_bwd(lib, dev, dtype, case):
         assert rel_err(rv.g, dy64) < tol
 
 
-@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16", "f16"])
 def test_conv_channel_slices(lib, dev, dtype):
     """Concat-free DecoderSampleCombiner (row slices + accumulate) and SkipScaler (output slices)."""
     from nvae_tf_amd import ops
@@ -166,8 +167,8 @@ def test_conv_channel_slices(lib, dev, dtype):
         dy = torch.randn(B, H // 2, H // 2, nch, generator=g)
         x64 = q(x, dtype).requires_grad_(True)
         o = x64 * torch.sigmoid(x64)
-        if dtype == torch.bfloat16:
-            o = o + (o.to(dtype).double() - o).detach()   # the kernel stores swish(x) in bf16
+        if dtype != torch.float32:
+            o = o + (o.to(dtype).double() - o).detach()   # the kernel stores swish(x) in the 16-bit activation type
         views = [o, o[:, 1:, 1:, :], o[:, :, 1:, :], o[:, 1:, :, :]]
         ws = [q(ps.get(f"{name}.conv{i + 1}.w").cpu(), dtype).requires_grad_(True) for i in range(4)]
         bs = [ps.get(f"{name}.conv{i + 1}.b").cpu().double() for i in range(4)]
@@ -185,7 +186,7 @@ def test_conv_channel_slices(lib, dev, dtype):
             assert rel_err(ps.get_grad(f"{name}.conv{i + 1}.w"), gr[1 + i]) < tol, (nch, i)
 
 
-@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16", "f16"])
 @pytest.mark.parametrize("act", [0, 1], ids=["none", "swish"])
 @pytest.mark.parametrize("shape", [(4, 4, 4, 32), (3, 8, 8, 192), (2, 4, 4, 1536), (5, 16, 16, 64)])
 def test_bn_act(lib, dev, dtype, act, shape):
@@ -318,7 +319,7 @@ FUSED_CHAIN_CASES = [
 ]
 
 
-@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16", "f16"])
 @pytest.mark.parametrize("case", FUSED_CHAIN_CASES, ids=lambda c: "B{B}_H{H}_{ci}-{cm}-{co}_k{k1}{k2}".format(**c))
 @pytest.mark.parametrize("mode", ["prologue+fin", "prologue", "materialised"])
 def test_fused_bn_chain(lib, dev, dtype, case, mode, monkeypatch):
@@ -381,7 +382,7 @@ def test_fused_bn_chain(lib, dev, dtype, case, mode, monkeypatch):
     assert rel_err(ps.get_state("bn.rm"), 0.95 * mean) < 1e-3
 
 
-@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16", "f16"])
 @pytest.mark.parametrize("shape", [(6, 4, 4, 256), (3, 8, 8, 72), (2, 16, 16, 64), (130, 4, 4, 128), (2, 32, 32, 32)])
 @pytest.mark.parametrize("lazy", [False, True], ids=["materialised", "lazy"])
 def test_fused_bn_se_chain(lib, dev, dtype, shape, lazy):
@@ -438,11 +439,11 @@ def test_fused_bn_se_chain(lib, dev, dtype, shape, lazy):
     for i, n in enumerate(names):
         # bn1's beta / gamma gradients are sums that BN2's mean subtraction nearly cancels: in bf16 their
         # rounding noise is O(30 %) of the (tiny) true value; the f32 run of the same kernels is exact
-        lim = 0.6 if (dtype == torch.bfloat16 and n.startswith("bn1.")) else 8 * tol
+        lim = {torch.bfloat16: 0.6, torch.float16: 0.1}.get(dtype, 8 * tol) if n.startswith("bn1.") else 8 * tol
         assert rel_err(ps.get_grad(n), gr[2 + i]) < lim, n
 
 
-@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16", "f16"])
 @pytest.mark.parametrize("shape,ss,bs", [((3, 8, 8, 128), 0.1, 1.0), ((4, 4, 4, 256), 1.0, 0.1), ((2, 32, 32, 32), 1.0, 0.1)])
 def test_se_residual(lib, dev, dtype, shape, ss, bs):
     from nvae_tf_amd import ops
@@ -475,7 +476,7 @@ def test_se_residual(lib, dev, dtype, shape, ss, bs):
         assert rel_err(ps.get_grad("se." + n), gr[2 + i]) < 4 * tol, n
 
 
-@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16", "f16"])
 @pytest.mark.parametrize("B,H,W_,C_", [(3, 8, 8, 96), (5, 4, 4, 1536), (2, 16, 16, 192), (2, 6, 10, 72), (3, 3, 2, 8),
                                        (40, 32, 32, 64)],
                          ids=["8x8", "4x4", "16x16", "ragged", "tiny", "many-tiles"])
@@ -508,7 +509,7 @@ def test_dwconv5(lib, dev, dtype, B, H, W_, C_):
     from nvae_tf_amd._lib import call, ptr
     # forward with fused BatchNorm statistics (bf16 ring kernel): column sums / sums of squares of the output
     rows = lib.nvae_dwconv5_stats_rows(ctx.dt, B, H, W_, C_)
-    assert (rows > 0) == (dtype == torch.bfloat16)
+    assert (rows > 0) == (dtype != torch.float32)
     if rows:
         slab = torch.zeros((rows, 2, C_), device=dev)          # accumulated into with atomics: must be zero
         y2 = torch.empty_like(y.t)
@@ -527,7 +528,7 @@ def _softclamp5(x):
     return 5.0 * torch.tanh(x / 5.0)
 
 
-@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16", "f16"])
 @pytest.mark.parametrize("group0", [True, False])
 def test_sampler_kl(lib, dev, dtype, group0):
     from nvae_tf_amd import ops, _lib as L
@@ -581,7 +582,7 @@ def test_sampler_kl(lib, dev, dtype, group0):
         assert rel_err(dv.g, gr[1]) < tol
 
 
-@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16", "f16"])
 def test_bernoulli_and_loss(lib, dev, dtype):
     from nvae_tf_amd import ops, _lib as L
     from nvae_tf_amd.ops import Var
@@ -659,6 +660,51 @@ def test_spectral_norm_and_weight_prep(lib, dev):
                 wd = ps.wcopies[c.wd_off:c.wd_off + c.cin * c.wd_ld].reshape(c.cin, c.k, c.k, c.cout)
                 want = wn.flip(0, 1).permute(2, 0, 1, 3)
                 assert rel_err(wd, want) < TOL[dtype], c.name
+
+
+def test_dynamic_loss_scale_kernels(lib, dev):
+    """nvae_grad_guard / nvae_adamax / nvae_loss_scale_update (the f16 path's device-side dynamic loss scaling): a clean
+    step is taken on gradient / scale and counted; a step with a non-finite gradient element is skipped and halves the
+    scale; NVAE_LS_GROWTH_STEPS clean steps double it; the seed kernels multiply by the scale."""
+    from nvae_tf_amd import _lib as L
+    g = torch.Generator().manual_seed(31)
+    n = 2048
+    p, gr = torch.randn(n, generator=g), torch.randn(n, generator=g) * 4.0          # gradient of the SCALED loss
+    m, u = torch.zeros(n), torch.zeros(n)
+    hyper = torch.zeros(L.HY_SIZE, device=dev)
+    hyper[L.HY_LR], hyper[L.HY_LSCALE], hyper[L.HY_GSCALE] = 1e-2, 4.0, 0.25
+    pd, gd, md, ud = (t.to(dev) for t in (p, gr, m, u))
+
+    def step():
+        L.call("nvae_grad_guard", L.ptr(gd), n, L.ptr(hyper))
+        L.call("nvae_adamax", L.ptr(pd), L.ptr(gd), L.ptr(md), L.ptr(ud), n, L.ptr(hyper), 0.9, 0.999, 1e-7)
+        L.call("nvae_loss_scale_update", L.ptr(hyper), 2.0 ** -24, 2.0 ** 16)
+    step()
+    g1 = gr.double() / 4.0
+    m_ref = 0.1 * g1; u_ref = g1.abs(); p_ref = p.double() - 1e-2 * m_ref / (u_ref + 1e-7)
+    assert rel_err(pd, p_ref) < 1e-6 and rel_err(md, m_ref) < 1e-6 and rel_err(ud, u_ref) < 1e-6
+    assert hyper.tolist()[3:7] == [0.25, 4.0, 1.0, 0.0]
+    # overflow: nothing moves, the scale halves, the flag is cleared for the next step
+    before = (pd.clone(), md.clone(), ud.clone())
+    gd[777] = float("inf")
+    step()
+    assert torch.equal(pd, before[0]) and torch.equal(md, before[1]) and torch.equal(ud, before[2])
+    assert hyper.tolist()[3:7] == [0.5, 2.0, 0.0, 0.0]
+    gd[777] = float("nan")
+    step()
+    assert torch.equal(pd, before[0]) and hyper.tolist()[3:7] == [1.0, 1.0, 0.0, 0.0]
+    # growth after 200 clean steps
+    gd[777] = 0.5
+    for _ in range(200):
+        step()
+    assert hyper.tolist()[3:7] == [0.5, 2.0, 0.0, 0.0] and not torch.equal(pd, before[0])
+    # the backward seeds carry the scale
+    logits = torch.randn(2, 4, 4, 8, generator=g).to(dev)
+    x = (torch.rand(2, 4, 4, 8, generator=g) < 0.3).float().to(dev)
+    d1, d2 = torch.empty_like(logits), torch.empty_like(logits)
+    L.call("nvae_bernoulli_bwd", L.F32, L.ptr(logits), L.ptr(x), L.ptr(d1), logits.numel(), 0.5, None)
+    L.call("nvae_bernoulli_bwd", L.F32, L.ptr(logits), L.ptr(x), L.ptr(d2), logits.numel(), 0.5, L.ptr(hyper))
+    assert rel_err(d2, d1.double() * 2.0) < 1e-6
 
 
 def test_adamax_unary_randn(lib, dev):

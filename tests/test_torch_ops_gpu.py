@@ -7,8 +7,8 @@ import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 
-TOL = {torch.float32: 2e-4, torch.bfloat16: 2.5e-2}
-DTYPES = [torch.float32, torch.bfloat16]
+TOL = {torch.float32: 2e-4, torch.bfloat16: 2.5e-2, torch.float16: 3e-3}
+DTYPES = [torch.float32, torch.bfloat16, torch.float16]
 CHECKS = ("test_schema", "test_autograd_registration", "test_faketensor")
 
 
@@ -28,7 +28,7 @@ def _leaf(shape, dev, dtype=torch.float32, scale=1.0, seed=0):
     return (torch.randn(shape, generator=g) * scale).to(dev, dtype).requires_grad_(True)
 
 
-@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16", "f16"])
 @pytest.mark.parametrize("k,B,H,cin,cout", [(1, 4, 8, 32, 64), (3, 4, 8, 32, 48), (5, 2, 16, 64, 192)])
 def test_conv2d_same(ops, dev, dtype, k, B, H, cin, cout):
     x = _leaf((B, H, H, cin), dev, dtype, seed=1)
@@ -46,7 +46,7 @@ def test_conv2d_same(ops, dev, dtype, k, B, H, cin, cout):
     assert y.dtype == dtype and w.grad.dtype == torch.float32
 
 
-@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16", "f16"])
 @pytest.mark.parametrize("B,H,C_", [(8, 4, 128), (3, 8, 64), (2, 12, 72)])
 def test_dwconv5(ops, dev, dtype, B, H, C_):
     x = _leaf((B, H, H, C_), dev, dtype, seed=4)
@@ -62,7 +62,7 @@ def test_dwconv5(ops, dev, dtype, B, H, C_):
     assert rel(y, yr) < t and rel(x.grad, xr.grad) < t and rel(w.grad, wr.grad) < t and rel(b.grad, br.grad) < t
 
 
-@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16", "f16"])
 @pytest.mark.parametrize("act", [0, 1], ids=["none", "swish"])
 def test_bn_act(ops, dev, dtype, act):
     B, H, C_ = 16, 4, 96
@@ -82,7 +82,7 @@ def test_bn_act(ops, dev, dtype, act):
     assert rel(x.grad, xr.grad) < 2 * t and rel(gamma.grad, gr.grad) < 2 * t and rel(beta.grad, br.grad) < 2 * t
 
 
-@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16", "f16"])
 def test_se_residual(ops, dev, dtype):
     B, H, C_, Hd = 6, 4, 128, 8
     x = _leaf((B, H, H, C_), dev, dtype, seed=9)
