@@ -403,12 +403,12 @@ class NVAE:
         return self._segments[part][2:]
 
     def sync_replicas(self):
-        """Re-align the replicas on rank 0's parameters and state.  The averaged gradients are
-        identical on every rank, but spectral normalisation rewrites W <- W / sigma in place with sigma
-        from f32 atomics, whose summation order differs per GPU: replicas drift by ~1 ulp per step.
-        train.py calls this at every epoch start (a 250 MB broadcast, ~1 ms over xGMI)."""
+        """Align the replicas on rank 0's parameters, state, optimizer slots and loss-scale state (start-up / resume).
+        During training nothing drifts: the all-reduced gradient is the same bits on every rank, Adamax is
+        elementwise and spectral normalisation is deterministic (sn.hip), so replicas stay bit-identical
+        (tests/test_dist_cli_gpu.py asserts it over five graphed steps without any re-broadcast)."""
         if self.reducer is not None:
-            for t in (self.ps.params, self.ps.state, self.ps.adam_m, self.ps.adam_u):
+            for t in (self.ps.params, self.ps.state, self.ps.adam_m, self.ps.adam_u, self.hyper):
                 self.reducer.broadcast_(t)
 
     def _dp_segments(self) -> bool:

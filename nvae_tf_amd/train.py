@@ -51,7 +51,8 @@ def train(args, model, train_data, test_data, rank=0, world=1):
     tb_img = EventWriter(os.path.join(args.tensorboard_log_dir, "images")) if tb is not None else None
     for epoch in range(args.resume_from, args.epochs):
         model.on_epoch_begin(epoch)
-        model.sync_replicas()       # data-parallel: bound the ulp drift of the replicas (models.sync_replicas)
+        if epoch == args.resume_from:
+            model.sync_replicas()   # data-parallel start-up / resume: one broadcast; replicas stay bit-identical afterwards
         t0, seen, logs = time.time(), 0, {"loss": [], "reconstruction_loss": [], "kl_loss": [], "bn_loss": []}
         for i, (images, _) in enumerate(train_data):
             images = images[rank::world] if world > 1 else images       # shard the batch over ranks

@@ -170,29 +170,33 @@ def test_rgb_configs_full_batch_properties(lib, dev, name, n_groups, dtype):
     # --- graph replay keeps training
     model.capture_train_step(x.shape, warmup=1)
     model._static_x.copy_(x)
-    before = model.ps.params.clone()
-    losses = []
-    for _ in range(24 if f16 else 16):
-        losses.append(model.train_step_graphed(None)["loss"].clone())
+    kl_first = float(kl.sum(0).mean())
+    losses, kls = [], []
+    for _ in range(24):
+        o = model.train_step_graphed(None)
+        losses.append(o["loss"].clone()); kls.append(o["kl_per_group"].sum(0).mean())
     torch.cuda.synchronize()
-    losses = [float(v) for v in losses]
+    losses, kls = [float(v) for v in losses], [float(v) for v in kls]
     if f16:
         # float16 at a RANDOM INITIALISATION of this 40-group network cannot take a step: the parameter gradients grow
         # by ~2x per group on the way back (1e7 at the last groups, 1e12 at the first decoder groups, 1e20 at the stem;
         # tools/diag_f16_where.py, profiles/r02_f16_gradient_range_c5.txt), more than float16's exponent range, so
         # every loss scale overflows somewhere.  What must hold: the dynamic scaler detects it, skips every such step
-        # and leaves parameters and optimizer state exactly as they were (bf16, same exponent range as f32, trains).
+        # and never lets a non-finite value into parameters or optimizer state (bf16, with f32's exponent range, trains).
         from nvae_tf_amd import _lib as L
         scale = float(model.hyper[L.HY_LSCALE])
         taken = float(model.ps.adam_u.max()) > 0
         print(f"float16 {name}: loss scale after {len(losses)} steps 2^{math.log2(scale):.0f}, steps taken: {taken}")
         assert bool(torch.isfinite(model.ps.params).all()) and bool(torch.isfinite(model.ps.adam_m).all())
-        assert taken or (torch.equal(model.ps.params, before) and scale < 2.0 ** -8)
+        # (a skipped step still runs the forward pass: spectral normalisation rewrites W <- W / sigma, BatchNorm moves its
+        # statistics; what a skipped step must not touch is the optimizer: both Adamax slots are still all zero)
+        assert taken or (float(model.ps.adam_m.abs().max()) == 0.0 and scale < 2.0 ** -8)
         assert all(math.isfinite(v) for v in losses)
         return
-    # (at initialisation the 30 / 40-group KL is ~1e7 nats and every step draws fresh latent noise, so single steps
-    # are not monotone; the trend over 16 steps is)
-    assert all(math.isfinite(v) for v in losses) and min(losses[-6:]) < first, (first, losses)
+    # At initialisation the 30 / 40-group KL is ~1e7 nats; while beta climbs the weighted loss rises for the first
+    # tens of steps (as in the reference's schedule) and every step draws fresh noise, so the property checked is that
+    # the KL itself - what the optimiser is being asked to bring down - falls by a large factor within 24 steps.
+    assert all(math.isfinite(v) for v in losses + kls) and min(kls[-6:]) < 0.7 * kl_first, (kl_first, kls)
 
     # --- sampling
     images, last_s, z1, z2 = model.sample(n_samples=8, temperature=0.8)
