@@ -969,19 +969,6 @@ __global__ __launch_bounds__(RED_THREADS) void k_bn_apply_fin(
     const T* __restrict__ x, T* __restrict__ y, long rows, int C, int rows_per_block,
     const float* __restrict__ partials, int S, BnFinArgs a, int act) {
     __shared__ float s_sc[64], s_sh[64];
-    const int TGS = C >= 64 ? 8 : (C > 16 ? (C > 32 ? 8 : 4) : (C > 8 ? 2 : 1));
-    const int RL = RED_THREADS / TGS;
-    const int tg = threadIdx.x % TGS, rl = threadIdx.x / TGS;
-    const int c0 = blockIdx.x * 64 + tg * 8;
-    const long r0 = (long)blockIdx.y * rows_per_block;
-    long r1 = r0 + rows_per_block;
-    if (r1 > rows) r1 = rows;
-    // the thread's first row is requested BEFORE the slab -> coefficient prologue (a dependent chain of an L2 round
-    // trip, f64 arithmetic and a barrier): most launches have one row per thread, so the prologue hides under the load
-    float v[8];
-    long r = r0 + rl;
-    const bool first = c0 < C && r < r1;
-    if (first) V8<T>::ld(x + r * (long)C + c0, v);
     {
         int c; double s1, s2;
         if (bn_slab_sum64_t<sizeof(T) == 4>(partials, S, C, blockIdx.x * 64, c, s1, s2)) {
@@ -998,20 +985,26 @@ __global__ __launch_bounds__(RED_THREADS) void k_bn_apply_fin(
         }
     }
     __syncthreads();
-    if (!first) return;
+    const int TGS = C >= 64 ? 8 : (C > 16 ? (C > 32 ? 8 : 4) : (C > 8 ? 2 : 1));
+    const int RL = RED_THREADS / TGS;
+    const int tg = threadIdx.x % TGS, rl = threadIdx.x / TGS;
+    const int c0 = blockIdx.x * 64 + tg * 8;
+    if (c0 >= C) return;
     float sc[8], sh[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) { sc[j] = s_sc[tg * 8 + j]; sh[j] = s_sh[tg * 8 + j]; }
-    for (;;) {
+    const long r0 = (long)blockIdx.y * rows_per_block;
+    long r1 = r0 + rows_per_block;
+    if (r1 > rows) r1 = rows;
+    for (long r = r0 + rl; r < r1; r += RL) {
+        float v[8];
+        V8<T>::ld(x + r * (long)C + c0, v);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const float p = v[j] * sc[j] + sh[j];
             v[j] = (act == ACT_SWISH) ? swishf_(p) : p;
         }
         V8<T>::st(y + r * (long)C + c0, v);
-        r += RL;
-        if (r >= r1) break;
-        V8<T>::ld(x + r * (long)C + c0, v);
     }
 }
 
@@ -1045,23 +1038,6 @@ __global__ __launch_bounds__(RED_THREADS) void k_bn_bwd_apply_fin(
     const T* __restrict__ x, const T* __restrict__ dy, T* dx, long rows, int C, int rows_per_block,
     const float* __restrict__ partials, int S, BnFinArgs a, const float* __restrict__ shift, int act, int acc) {
     __shared__ float s_sc[64], s_sh[64], s_k0[64], s_k1[64];
-    const int TGS = C >= 64 ? 8 : (C > 16 ? (C > 32 ? 8 : 4) : (C > 8 ? 2 : 1));
-    const int RL = RED_THREADS / TGS;
-    const int tg = threadIdx.x % TGS, rl = threadIdx.x / TGS;
-    const int c0 = blockIdx.x * 64 + tg * 8;
-    const long r0 = (long)blockIdx.y * rows_per_block;
-    long r1 = r0 + rows_per_block;
-    if (r1 > rows) r1 = rows;
-    // first row requested before the slab -> coefficient prologue (see k_bn_apply_fin)
-    float v[8], g[8], o[8];
-    long r = r0 + rl;
-    const bool first = c0 < C && r < r1;
-    if (first) {
-        const long off = r * (long)C + c0;
-        V8<T>::ld(x + off, v);
-        V8<T>::ld(dy + off, g);
-        if (acc) V8<T>::ld(dx + off, o);
-    }
     {
         int c; double s1, s2;
         if (bn_slab_sum64_t<sizeof(T) == 4>(partials, S, C, blockIdx.x * 64, c, s1, s2)) {
@@ -1072,14 +1048,25 @@ __global__ __launch_bounds__(RED_THREADS) void k_bn_bwd_apply_fin(
         }
     }
     __syncthreads();
-    if (!first) return;
+    const int TGS = C >= 64 ? 8 : (C > 16 ? (C > 32 ? 8 : 4) : (C > 8 ? 2 : 1));
+    const int RL = RED_THREADS / TGS;
+    const int tg = threadIdx.x % TGS, rl = threadIdx.x / TGS;
+    const int c0 = blockIdx.x * 64 + tg * 8;
+    if (c0 >= C) return;
     float sc[8], sh[8], k0[8], k1[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         sc[j] = s_sc[tg * 8 + j]; sh[j] = s_sh[tg * 8 + j]; k0[j] = s_k0[tg * 8 + j]; k1[j] = s_k1[tg * 8 + j];
     }
-    for (;;) {
+    const long r0 = (long)blockIdx.y * rows_per_block;
+    long r1 = r0 + rows_per_block;
+    if (r1 > rows) r1 = rows;
+    for (long r = r0 + rl; r < r1; r += RL) {
         const long off = r * (long)C + c0;
+        float v[8], g[8], o[8];
+        V8<T>::ld(x + off, v);
+        V8<T>::ld(dy + off, g);
+        if (acc) V8<T>::ld(dx + off, o);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             float dpre = g[j];
@@ -1087,12 +1074,6 @@ __global__ __launch_bounds__(RED_THREADS) void k_bn_bwd_apply_fin(
             o[j] = (acc ? o[j] : 0.f) + sc[j] * dpre + k1[j] * v[j] + k0[j];
         }
         V8<T>::st(dx + off, o);
-        r += RL;
-        if (r >= r1) break;
-        const long off2 = r * (long)C + c0;
-        V8<T>::ld(x + off2, v);
-        V8<T>::ld(dy + off2, g);
-        if (acc) V8<T>::ld(dx + off2, o);
     }
 }
 

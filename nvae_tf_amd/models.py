@@ -25,6 +25,9 @@ from .preprocess import Preprocess
 
 ADAMAX_B1, ADAMAX_B2, ADAMAX_EPS = 0.9, 0.999, 1e-7   # Keras Adamax defaults [3P], train.py:131
 # single-GPU overlap of the step's HBM-bound bookkeeping with its launch-bound compute (both default on):
+# per-step scalars uploaded without a host sync: measured SLOWER (6 097-6 144 vs 6 211-6 225 images/s on one box) - with
+# the host running ahead, the next step's side-stream prologue competes with the tail of the current step
+ASYNC_HYPER = os.environ.get("NVAE_ASYNC_HYPER", "0") != "0"
 OVERLAP_PREP = os.environ.get("NVAE_OVERLAP_PREP", "1") != "0"      # SN + weight copies of later modules on the side stream
 # Adamax of a finished backward segment on the side stream: measured SLOWER (21.1-21.3 vs 20.4 ms/step) - cutting the
 # backward pass into segments flushes the weight-gradient queue five times, and smaller same-shape batches cost more
@@ -318,9 +321,8 @@ class NVAE:
         beta = self.beta()
         t = self.opt_iterations + 1
         lr_t = self.learning_rate(self.opt_iterations) / (1 - ADAMAX_B1 ** t)
-        # slots 0..2 come from the host every step (slots 3.. hold the loss-scale state, maintained on the device).
-        # The copy is asynchronous out of a small ring of pinned buffers: a blocking copy would make the host wait
-        # for the previous step to drain before it can enqueue the next step's graphs.
+        # slots 0..2 come from the host every step (slots 3.. hold the loss-scale state, maintained on the device),
+        # out of a small ring of pinned buffers; blocking by default (ASYNC_HYPER above)
         if self._hyper_ring is None:
             self._hyper_ring = [[torch.zeros(3, dtype=torch.float32).pin_memory(), None] for _ in range(8)]
             self._hyper_slot = 0
@@ -330,7 +332,7 @@ class NVAE:
             slot[1].synchronize()                      # the copy that last used this buffer (8 steps ago) has run
         h = slot[0]
         h[L.HY_LR], h[L.HY_BETA], h[L.HY_BALANCE] = lr_t, beta, 1.0 if beta < 1 else 0.0
-        self.hyper[:3].copy_(h, non_blocking=True)
+        self.hyper[:3].copy_(h, non_blocking=ASYNC_HYPER)
         slot[1] = torch.cuda.Event()
         slot[1].record()
 

@@ -104,7 +104,8 @@ def _fullsize_f16(bench, dev):
     losses = [float(v) for v in losses]
     assert all(math.isfinite(v) for v in losses) and bool(torch.isfinite(model.ps.params).all())
     assert min(losses[-10:]) < 0.75 * losses[0], losses[::6]
-    assert float(model.hyper[L.HY_GOOD]) == 60.0 and float(model.hyper[L.HY_LSCALE]) == 2.0 ** -8     # no step skipped
+    # (measured: no step skipped in 400; allow for one overflow, which halves the scale and restarts the count)
+    assert float(model.hyper[L.HY_GOOD]) >= 30.0 and float(model.hyper[L.HY_LSCALE]) >= 2.0 ** -9
 
 
 # ---------------------------------------------------------------------------------------------------------
