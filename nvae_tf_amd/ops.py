@@ -70,6 +70,7 @@ CONV_PRE = os.environ.get("NVAE_CONV_PRE", "1")
 # 4.8 us of a finalize launch or the ~0 of a consumer that reads the accumulated slab itself, so off by default
 STATS_FIN = os.environ.get("NVAE_STATS_FIN", "0") != "0"
 FUSE_BN_BWD = os.environ.get("NVAE_BN_BWD_FUSE", "1") != "0"   # BN backward sums in the dgrad epilogue
+BN_BWD_SPLIT = os.environ.get("NVAE_BN_BWD_SPLIT", "0") != "0"  # unfused BN backward: reduce + self-finishing apply
 
 
 class Ctx:
@@ -609,6 +610,13 @@ def bn_act(ctx: Ctx, x: Var, bn, act: int = L.ACT_NONE, lazy: bool = True) -> Va
                          ptr(info["k0k1"]), act, acc)
                 return
             part = ctx.empty_slab(S, Cc)
+            if BN_BWD_SPLIT and APPLY_FIN and x.needs_grad:
+                # plain strip reduce (no last-arriver hand-off) + the apply pass that finishes the slab itself
+                call("nvae_bn_bwd_reduce", ctx.dt, ptr(xt), ptr(y.g), rows, Cc, scale, shift, act, ptr(part))
+                g, acc = ctx.grad_of(x)
+                call("nvae_bn_bwd_apply_fin", ctx.dt, ptr(xt), ptr(y.g), ptr(g), rows, Cc, ptr(part), S, scale, shift,
+                     mean, invstd, dgamma, dbeta, act, frozen, acc)
+                return
             k0k1 = ctx.empty((2, Cc), torch.float32)
             if FUSED_FIN:
                 call("nvae_bn_bwd_reduce_fin", ctx.dt, ptr(xt), ptr(y.g), rows, Cc, scale, shift, mean, invstd,

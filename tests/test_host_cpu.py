@@ -156,3 +156,32 @@ def test_torch_library_registration():
     assert ops.bernoulli_nll(torch.empty(2, 32, 32, 1, device="meta"), torch.empty(2, 32, 32, 1, device="meta")).shape == (2,)
     with pytest.raises(NotImplementedError):
         ops.conv2d_same(torch.zeros(2, 8, 8, 32), torch.zeros(3, 3, 32, 64), None)
+
+
+def test_weight_preparation_parts_tile_the_conv_list(lib):
+    """ParamStore.prepare_weights(part=k): the four per-module descriptor tables (preprocess | encoder | decoder |
+    postprocess) cover every conv exactly once, their workgroup numbering restarts at 0 in each part and is otherwise
+    the global numbering, and float16 models default to the device-side dynamic loss scale."""
+    import ctypes as C
+    from nvae_tf_amd import _lib as L
+    m = make([5, 10], 2)
+    ps = m.ps
+    assert ps.n_prep_parts() == 4 and ps.prep_marks[0] == 0 and ps.prep_marks[-1] == len(ps.convs)
+    full = (L.ConvDesc * len(ps.convs)).from_buffer_copy(ps.descs.numpy().tobytes())
+    reb = (L.ConvDesc * len(ps.convs)).from_buffer_copy(ps.descs_parts.numpy().tobytes())
+    n_total = blocks_total = 0
+    for k, (off, n, blocks) in enumerate(ps._parts):
+        i0 = off // C.sizeof(L.ConvDesc)
+        assert i0 == ps.prep_marks[k] and n == ps.prep_marks[k + 1] - ps.prep_marks[k] and n > 0
+        assert reb[i0].blk_off == 0
+        for i in range(i0, i0 + n):
+            assert reb[i].blk_off == full[i].blk_off - full[i0].blk_off
+            assert (reb[i].w_off, reb[i].t_off, reb[i].p_off, reb[i].idx) == (full[i].w_off, full[i].t_off, full[i].p_off, full[i].idx)
+        last = i0 + n - 1
+        assert blocks == reb[last].blk_off + (full[last].K + 15) // 16
+        n_total += n; blocks_total += blocks
+    assert n_total == len(ps.convs) and blocks_total == ps.sn_blocks
+    assert not m.dynamic_loss_scale and m.loss_scale == 1.0
+    m16 = make([1, 1], 1, dtype=torch.float16)
+    assert m16.dynamic_loss_scale and float(m16.hyper[L.HY_LSCALE]) == 2.0 ** -8 and float(m16.hyper[L.HY_GSCALE]) == 256.0
+    assert not make([1, 1], 1, dtype=torch.float16, loss_scale=4.0).dynamic_loss_scale
