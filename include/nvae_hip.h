@@ -183,6 +183,14 @@ int nvae_dwconv5_stats(int dtype, const void* x, const float* w, const float* bi
                        int W, int C, float* stats, void* stream);
 int nvae_dwconv5_wgrad(int dtype, const void* x, const void* dy, float* dw, float* db, int B, int H,
                        int W, int C, void* stream);
+/* The same two passes on act(BN(x)) of the RAW tensor x (decoder.py:125-131: BatchNormalization -> swish ->
+ * DepthwiseConv2D), 16-bit activation types: the BatchNorm is applied to the halo tile in LDS and the normalised
+ * activation is never materialised.  Forward: bn = the final table or the producer's statistics slab (as for
+ * nvae_se_fused_fwd); weight gradient: the final scale / shift table.                                        */
+int nvae_dwconv5_pre(int dtype, const void* x, const NvaeBnIn* bn, int act, const float* w, const float* bias,
+                     void* y, int B, int H, int W, int C, float* stats /* NULL or output slab */, void* stream);
+int nvae_dwconv5_wgrad_pre(int dtype, const void* x, const float* scale, const float* shift, int act,
+                           const void* dy, float* dw, float* db, int B, int H, int W, int C, void* stream);
 
 /* ---- BatchNormalization(momentum=.05, eps=1e-5) (+Swish), encoder.py:91-103, decoder.py:125-146,
  *      postprocess.py:71,84,107-108, preprocess.py:88-89, common.py:148,165-166 ------------------- */

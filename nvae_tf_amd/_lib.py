@@ -77,6 +77,8 @@ _SIGS = {
     "nvae_colsum": [_i, _p, _l, _i, _i, _p],
     "nvae_dwconv5": [_i, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i],
     "nvae_dwconv5_wgrad": [_i, _p, _p, _p, _p, _i, _i, _i, _i],
+    "nvae_dwconv5_pre": [_i, _p, _p, _i, _p, _p, _p, _i, _i, _i, _i, _p],
+    "nvae_dwconv5_wgrad_pre": [_i, _p, _p, _p, _i, _p, _p, _p, _i, _i, _i, _i],
     "nvae_dwconv5_stats": [_i, _p, _p, _p, _p, _i, _i, _i, _i, _p],
     "nvae_reduce_splits": None,
     "nvae_dwconv5_stats_rows": None,

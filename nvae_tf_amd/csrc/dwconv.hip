@@ -16,6 +16,7 @@
 // CIFAR-10 shape B64 x 16x16 x 1536 took 173 us forward and 1 180 us for the weight gradient, i.e.
 // 0.6 / 0.08 TB/s of algorithmic traffic.
 #include "common.h"
+#include "bn_fin.h"
 #include "conv_common.h"      // glds16 (LDS-DMA), wait_vmcnt, zero_page
 
 #define DW_CC 64          // channels per workgroup
@@ -172,12 +173,46 @@ template <> __device__ __forceinline__ unsigned dw_pack<f16>(dw_f2 v) {
     return __builtin_bit_cast(unsigned, h);
 }
 
+
+// Operand prologue of the 16-bit ring kernels (round 2): the input is act(BN(x)) of the RAW tensor x, never
+// materialised.  A thread DMA's 16-B chunks of a fixed 8-channel group (q & 7 == lane & 7), so it keeps that group's
+// scale / shift in registers and transforms ITS OWN chunks in LDS right after its vmcnt wait and before the barrier
+// that publishes the stage (no extra barrier); out-of-image chunks (the 'same' padding, DMA'd from the zero page) stay
+// zero, because the padding applies to the activated tensor.  The whole image is one tile at 4x4 / 8x8, so every
+// element is transformed exactly once per pass.
+struct DwPre { BnFromSlab bn; int on; int act; };
+template <typename T>
+__device__ __forceinline__ void dw_pre_coefs(const DwPre& pre, int C, int c_base, float (&sc)[8], float (&sh)[8]) {
+    __shared__ float t_sc[DW_CC], t_sh[DW_CC];
+    if (threadIdx.x < DW_CC) {
+        const int c = c_base + threadIdx.x;
+        float a = 0.f, b = 0.f;
+        if (c < C) bn_coef<sizeof(T) == 4>(pre.bn, C, c, blockIdx.y == 0, a, b);
+        t_sc[threadIdx.x] = a; t_sh[threadIdx.x] = b;
+    }
+    __syncthreads();
+    const int g8 = (threadIdx.x & 7) * 8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { sc[j] = t_sc[g8 + j]; sh[j] = t_sh[g8 + j]; }
+}
+template <typename T>
+__device__ __forceinline__ uint4 dw_pre_chunk(uint4 raw, const float (&sc)[8], const float (&sh)[8], int act) {
+    float v[8];
+    unpack8<T>(raw, v);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float p = v[j] * sc[j] + sh[j];
+        v[j] = act == ACT_SWISH ? swishf_(p) : p;
+    }
+    return pack8<T>(v);
+}
+
 template <typename T, int TH, int TW, int IMGS>
 __global__ __launch_bounds__(256, 2) void k_dw5_fwd_ring(const T* __restrict__ x, const float* __restrict__ w,
                                                       const float* __restrict__ bias, T* y, int B, int H,
                                                       int W, int C, int tiles_x, int tiles_per_img, int flip,
                                                       int acc, const uint4* __restrict__ zeros,
-                                                      float* __restrict__ stats) {
+                                                      float* __restrict__ stats, DwPre pre) {
     static_assert(IMGS * (TH / 2) * (TW / 4) == 8, "8 pixel lanes of 2x4 outputs per workgroup");
     constexpr int NS = 2;
     constexpr int HTH = TH + 4, HTW = TW + 4, NCH = IMGS * HTH * HTW * 8;     // 16-B chunks per unit
@@ -213,10 +248,11 @@ __global__ __launch_bounds__(256, 2) void k_dw5_fwd_ring(const T* __restrict__ x
             b = u * IMGS; ty = 0; tx = 0;
         }
     };
-    auto issue = [&](int i) {
+    auto issue = [&](int i) -> unsigned {       // returns the mask of this thread's chunks that hold image data
         long b; int ty, tx;
         unit_of(i, b, ty, tx);
         const unsigned dst = lds_base + (unsigned)((i % NS) * STAGE) * 16u;
+        unsigned mask = 0;
 #pragma unroll
         for (int k = 0; k < KI; ++k) {
             const int q = (k * 4 + wave) * 64 + lane;
@@ -227,17 +263,32 @@ __global__ __launch_bounds__(256, 2) void k_dw5_fwd_ring(const T* __restrict__ x
             const bool ok = q < NCH && b + img < B && gy >= 0 && gy < H && gx >= 0 && gx < W && c_base + cc < C;
             const void* p = ok ? (const void*)(x + ((((b + img) * H + gy) * (long)W + gx) * C + c_base + cc)) : (const void*)zeros;
             glds16(p, dst + (unsigned)((k * 4 + wave) * 64) * 16u);
+            mask |= (ok ? 1u : 0u) << k;
         }
+        return mask;
     };
-    if (nmine > 0) issue(0);
+    float psc[8], psh[8];
+    if (pre.on) dw_pre_coefs<T>(pre, C, c_base, psc, psh);
+    unsigned mask_cur = 0, mask_next = 0;
+    if (nmine > 0) mask_cur = issue(0);
     // pixel lane -> (image within the unit, 2-row block, 4-column block)
     constexpr int CB = TW / 4, RB = TH / 2;
     const int cb = pl % CB, rb = (pl / CB) % RB, img = pl / (CB * RB);
     dw_f2 st1 = {0.f, 0.f}, st2 = {0.f, 0.f};       // BatchNorm statistics of this thread's outputs (stats != NULL)
     for (int i = 0; i < nmine; ++i) {
         wait_vmcnt<0>();             // this wave's part of unit i has landed (and its older y stores)
+        if (pre.on) {
+            uint4* st = lds + (i % NS) * STAGE;
+#pragma unroll
+            for (int k = 0; k < KI; ++k)
+                if (mask_cur & (1u << k)) {
+                    uint4* slot = st + (k * 4 + wave) * 64 + lane;
+                    *slot = dw_pre_chunk<T>(*slot, psc, psh, pre.act);
+                }
+        }
         __syncthreads();             // everyone's part is in LDS; everyone finished reading stage (i+1) % 2
-        if (i + 1 < nmine) issue(i + 1);
+        if (i + 1 < nmine) mask_next = issue(i + 1);
+        const unsigned mask_keep = mask_next;
         long b; int ty, tx;
         unit_of(i, b, ty, tx);
         b += img;
@@ -282,6 +333,7 @@ __global__ __launch_bounds__(256, 2) void k_dw5_fwd_ring(const T* __restrict__ x
                         st2 += o[r][p] * o[r][p];
                     }
         }
+        mask_cur = mask_keep;
     }
     if (stats) {
         // per-workgroup column sums, accumulated into the (zeroed) slab nvae_bn_finalize_s / nvae_bn_apply_fin consume
@@ -325,8 +377,24 @@ extern "C" int nvae_dwconv5_stats_rows(int dtype, int B, int H, int W, int C) {
     return cdiv(dw_ring_rows(B, H, W, C), 64);
 }
 
+static int dw_pre_from(const char* who, const NvaeBnIn* in, int act, long rows, DwPre& pre) {
+    pre = DwPre{};
+    if (!in) return NVAE_OK;
+    NVAE_REQUIRE(in->scale && in->shift, "%s: NvaeBnIn needs scale / shift", who);
+    NVAE_REQUIRE(act == ACT_NONE || act == ACT_SWISH, "%s: act %d unsupported", who, act);
+    pre.on = 1; pre.act = act;
+    pre.bn.scale = in->scale; pre.bn.shift = in->shift; pre.bn.mean = in->mean; pre.bn.invstd = in->invstd;
+    if (in->slab) {
+        NVAE_REQUIRE(in->rows > 0 && in->gamma && in->beta && in->rm && in->rv && in->mean && in->invstd,
+                     "%s: NvaeBnIn with a slab needs rows, gamma, beta, rm, rv, mean, invstd", who);
+        pre.bn.slab = in->slab; pre.bn.rows = in->rows; pre.bn.inv_n = 1.0f / (float)rows; pre.bn.eps = in->eps;
+        pre.bn.momentum = in->momentum; pre.bn.gamma = in->gamma; pre.bn.beta = in->beta; pre.bn.rm = in->rm; pre.bn.rv = in->rv;
+    }
+    return NVAE_OK;
+}
+
 static int dwconv5_impl(int dtype, const void* x, const float* w, const float* bias, void* y, int B, int H, int W,
-                        int C, int flip, int accumulate, float* stats, void* stream) {
+                        int C, int flip, int accumulate, float* stats, void* stream, const DwPre& pre = DwPre{}) {
     NVAE_REQUIRE(B > 0 && H > 0 && W > 0 && C >= 8 && C % 8 == 0, "dwconv5: bad shape");
     NVAE_REQUIRE(aligned16(x) && aligned16(y) && aligned16(w) && (!bias || aligned16(bias)), "dwconv5: alignment");
     NVAE_REQUIRE(!stats || (is16(dtype) && !flip && !accumulate), "dwconv5: statistics only from the 16-bit forward");
@@ -338,14 +406,15 @@ static int dwconv5_impl(int dtype, const void* x, const float* w, const float* b
         dim3 grid(strips, (unsigned)dw_ring_rows(B, H, W, C));
 #define DW_RING(T_)                                                                                              \
         if (small)                                                                                               \
-            hipLaunchKernelGGL((k_dw5_fwd_ring<T_, 4, 4, 4>), grid, 256, 0, (hipStream_t)stream, (const T_*)x, w, bias, (T_*)y, B, H, W, C, tx, tx * ty, flip, accumulate, zero_page(), stats); \
+            hipLaunchKernelGGL((k_dw5_fwd_ring<T_, 4, 4, 4>), grid, 256, 0, (hipStream_t)stream, (const T_*)x, w, bias, (T_*)y, B, H, W, C, tx, tx * ty, flip, accumulate, zero_page(), stats, pre); \
         else                                                                                                     \
-            hipLaunchKernelGGL((k_dw5_fwd_ring<T_, 8, 8, 1>), grid, 256, 0, (hipStream_t)stream, (const T_*)x, w, bias, (T_*)y, B, H, W, C, tx, tx * ty, flip, accumulate, zero_page(), stats);
+            hipLaunchKernelGGL((k_dw5_fwd_ring<T_, 8, 8, 1>), grid, 256, 0, (hipStream_t)stream, (const T_*)x, w, bias, (T_*)y, B, H, W, C, tx, tx * ty, flip, accumulate, zero_page(), stats, pre);
         if (dtype == NVAE_BF16) { DW_RING(bf16) } else { DW_RING(f16) }
 #undef DW_RING
         NVAE_LAUNCH_CHECK("dwconv5");
         return NVAE_OK;
     }
+    NVAE_REQUIRE(!pre.on, "dwconv5_pre: the operand prologue exists for the 16-bit activation types only");
     if (H <= 4 && W <= 4) {
         dim3 grid(strips, 1, B);
         DISPATCH_T(dtype, hipLaunchKernelGGL((k_dw5_fwd<T, 4, 4, 1>), grid, 256, 0, (hipStream_t)stream, (const T*)x, w, bias, (T*)y, H, W, C, 1, flip, accumulate);)
@@ -371,6 +440,17 @@ extern "C" int nvae_dwconv5_stats(int dtype, const void* x, const float* w, cons
                                   int H, int W, int C, float* stats, void* stream) {
     NVAE_REQUIRE(stats, "dwconv5_stats: NULL statistics slab");
     return dwconv5_impl(dtype, x, w, bias, y, B, H, W, C, 0, 0, stats, stream);
+}
+
+// Forward pass on act(BN(x)) of the RAW tensor x (16-bit activation types): the BatchNorm in front - given as its
+// final table or as the statistics slab its producer left (NvaeBnIn, as for nvae_se_fused_fwd) - is applied to the
+// halo tile in LDS, the normalised activation is never written.  stats: NULL or the output's statistics slab.
+extern "C" int nvae_dwconv5_pre(int dtype, const void* x, const NvaeBnIn* bn, int act, const float* w,
+                                const float* bias, void* y, int B, int H, int W, int C, float* stats, void* stream) {
+    NVAE_REQUIRE(bn && is16(dtype), "dwconv5_pre: needs a BatchNorm description and a 16-bit activation type");
+    DwPre pre;
+    if (int e = dw_pre_from("dwconv5_pre", bn, act, (long)B * H * W, pre)) return e;
+    return dwconv5_impl(dtype, x, w, bias, y, B, H, W, C, 0, 0, stats, stream, pre);
 }
 
 // dw[kh,kw,c] += sum_{b,h,w} x[b,h+kh-2,w+kw-2,c] * dy[b,h,w,c];  db[c] += sum dy.
@@ -477,7 +557,7 @@ template <typename T, int TH, int TW, int IMGS>
 __global__ __launch_bounds__(256, 2) void k_dw5_wgrad_ring(const T* __restrict__ x, const T* __restrict__ dy,
                                                            float* dw, float* db, int B, int H, int W, int C,
                                                            int tiles_x, int tiles_per_img,
-                                                           const uint4* __restrict__ zeros) {
+                                                           const uint4* __restrict__ zeros, DwPre pre) {
     static_assert(IMGS * (TH / 2) * (TW / 4) == 8, "8 pixel lanes of 2x4 dy pixels per workgroup");
     constexpr int NS = 2;
     constexpr int HTH = TH + 4, HTW = TW + 4;
@@ -499,9 +579,10 @@ __global__ __launch_bounds__(256, 2) void k_dw5_wgrad_ring(const T* __restrict__
     dw_f2 ab = {0.f, 0.f};
     const long units = IMGS == 1 ? (long)B * tiles_per_img : (long)(B + IMGS - 1) / IMGS;
     const int nmine = blockIdx.y < units ? (int)((units - blockIdx.y + gridDim.y - 1) / gridDim.y) : 0;
-    auto issue = [&](int i) {
+    auto issue = [&](int i) -> unsigned {       // returns the mask of this thread's x chunks that hold image data
         const long u = blockIdx.y + (long)i * gridDim.y;
         long b; int ty, tx;
+        unsigned mask = 0;
         if (IMGS == 1) {
             b = u / tiles_per_img;
             const int tile = (int)(u - b * tiles_per_img);
@@ -520,6 +601,7 @@ __global__ __launch_bounds__(256, 2) void k_dw5_wgrad_ring(const T* __restrict__
             const bool ok = q < XCH && b + im < B && gy >= 0 && gy < H && gx >= 0 && gx < W && c_base + cc < C;
             const void* p = ok ? (const void*)(x + ((((b + im) * H + gy) * (long)W + gx) * C + c_base + cc)) : (const void*)zeros;
             glds16(p, dst + (unsigned)((k * 4 + wave) * 64) * 16u);
+            mask |= (ok ? 1u : 0u) << k;
         }
 #pragma unroll
         for (int k = 0; k < KD; ++k) {
@@ -532,12 +614,25 @@ __global__ __launch_bounds__(256, 2) void k_dw5_wgrad_ring(const T* __restrict__
             const void* p = ok ? (const void*)(dy + ((((b + im) * H + gy) * (long)W + gx) * C + c_base + cc)) : (const void*)zeros;
             glds16(p, dst + (unsigned)(KX * 256 + (k * 4 + wave) * 64) * 16u);
         }
+        return mask;
     };
-    if (nmine > 0) issue(0);
-    for (int i = 0; i < nmine; ++i) {
+    float psc[8], psh[8];
+    if (pre.on) dw_pre_coefs<T>(pre, C, c_base, psc, psh);
+    unsigned mask_cur = 0, mask_next = 0;
+    if (nmine > 0) mask_cur = issue(0);
+    for (int i = 0; i < nmine; ++i, mask_cur = mask_next) {
         wait_vmcnt<0>();
+        if (pre.on) {
+            uint4* st = lds + (i % NS) * STAGE;
+#pragma unroll
+            for (int k = 0; k < KX; ++k)
+                if (mask_cur & (1u << k)) {
+                    uint4* slot = st + (k * 4 + wave) * 64 + lane;
+                    *slot = dw_pre_chunk<T>(*slot, psc, psh, pre.act);
+                }
+        }
         __syncthreads();
-        if (i + 1 < nmine) issue(i + 1);
+        if (i + 1 < nmine) mask_next = issue(i + 1);
         const T* sx = (const T*)(lds + (i % NS) * STAGE) + (long)img * HTH * HTW * DW_CC;
         const T* sd = (const T*)(lds + (i % NS) * STAGE) + KX * 256 * 8 + (long)img * TH * TW * DW_CC;
         dw_f2 g[2][4];
@@ -594,8 +689,8 @@ __global__ __launch_bounds__(256, 2) void k_dw5_wgrad_ring(const T* __restrict__
     }
 }
 
-extern "C" int nvae_dwconv5_wgrad(int dtype, const void* x, const void* dy, float* dw, float* db, int B,
-                                  int H, int W, int C, void* stream) {
+static int dwconv5_wgrad_impl(int dtype, const void* x, const void* dy, float* dw, float* db, int B,
+                              int H, int W, int C, void* stream, const DwPre& pre) {
     NVAE_REQUIRE(B > 0 && H > 0 && W > 0 && C >= 8 && C % 8 == 0 && x && dy && dw, "dwconv5_wgrad: bad args");
     NVAE_REQUIRE(aligned16(x) && aligned16(dy), "dwconv5_wgrad: alignment");
     const int strips = cdiv(C, DW_CC);
@@ -615,9 +710,9 @@ extern "C" int nvae_dwconv5_wgrad(int dtype, const void* x, const void* dy, floa
     dim3 grid(strips, (unsigned)chunks);
     if (is16(dtype) && !small) {
         if (dtype == NVAE_BF16)
-            hipLaunchKernelGGL((k_dw5_wgrad_ring<bf16, 8, 8, 1>), grid, 256, 0, (hipStream_t)stream, (const bf16*)x, (const bf16*)dy, dw, db, B, H, W, C, tx, tx * ty, zero_page());
+            hipLaunchKernelGGL((k_dw5_wgrad_ring<bf16, 8, 8, 1>), grid, 256, 0, (hipStream_t)stream, (const bf16*)x, (const bf16*)dy, dw, db, B, H, W, C, tx, tx * ty, zero_page(), pre);
         else
-            hipLaunchKernelGGL((k_dw5_wgrad_ring<f16, 8, 8, 1>), grid, 256, 0, (hipStream_t)stream, (const f16*)x, (const f16*)dy, dw, db, B, H, W, C, tx, tx * ty, zero_page());
+            hipLaunchKernelGGL((k_dw5_wgrad_ring<f16, 8, 8, 1>), grid, 256, 0, (hipStream_t)stream, (const f16*)x, (const f16*)dy, dw, db, B, H, W, C, tx, tx * ty, zero_page(), pre);
         NVAE_LAUNCH_CHECK("dwconv5_wgrad");
         return NVAE_OK;
     }
@@ -629,12 +724,13 @@ extern "C" int nvae_dwconv5_wgrad(int dtype, const void* x, const void* dy, floa
         if (w4 > u4) w4 = u4;
         if (w4 < 1) w4 = 1;
         if (dtype == NVAE_BF16)
-            hipLaunchKernelGGL((k_dw5_wgrad_ring<bf16, 4, 4, 4>), dim3(strips, (unsigned)w4), 256, 0, (hipStream_t)stream, (const bf16*)x, (const bf16*)dy, dw, db, B, H, W, C, 1, 1, zero_page());
+            hipLaunchKernelGGL((k_dw5_wgrad_ring<bf16, 4, 4, 4>), dim3(strips, (unsigned)w4), 256, 0, (hipStream_t)stream, (const bf16*)x, (const bf16*)dy, dw, db, B, H, W, C, 1, 1, zero_page(), pre);
         else
-            hipLaunchKernelGGL((k_dw5_wgrad_ring<f16, 4, 4, 4>), dim3(strips, (unsigned)w4), 256, 0, (hipStream_t)stream, (const f16*)x, (const f16*)dy, dw, db, B, H, W, C, 1, 1, zero_page());
+            hipLaunchKernelGGL((k_dw5_wgrad_ring<f16, 4, 4, 4>), dim3(strips, (unsigned)w4), 256, 0, (hipStream_t)stream, (const f16*)x, (const f16*)dy, dw, db, B, H, W, C, 1, 1, zero_page(), pre);
         NVAE_LAUNCH_CHECK("dwconv5_wgrad");
         return NVAE_OK;
     }
+    NVAE_REQUIRE(!pre.on, "dwconv5_wgrad_pre: the operand prologue exists for the 16-bit activation types only");
     if (small) {
         DISPATCH_T(dtype, hipLaunchKernelGGL((k_dw5_wgrad<T, 4, 4, 1>), grid, 256, 0, (hipStream_t)stream, (const T*)x, (const T*)dy, dw, db, B, H, W, C, tx, tx * ty, (int)upb);)
     } else {
@@ -642,4 +738,20 @@ extern "C" int nvae_dwconv5_wgrad(int dtype, const void* x, const void* dy, floa
     }
     NVAE_LAUNCH_CHECK("dwconv5_wgrad");
     return NVAE_OK;
+}
+
+extern "C" int nvae_dwconv5_wgrad(int dtype, const void* x, const void* dy, float* dw, float* db, int B,
+                                  int H, int W, int C, void* stream) {
+    return dwconv5_wgrad_impl(dtype, x, dy, dw, db, B, H, W, C, stream, DwPre{});
+}
+
+// Weight gradient against act(BN(x)) of the RAW tensor x, with the BatchNorm's FINAL coefficient table (the backward
+// pass runs after the table was published): the counterpart of nvae_dwconv5_pre, 16-bit activation types only.
+extern "C" int nvae_dwconv5_wgrad_pre(int dtype, const void* x, const float* scale, const float* shift, int act,
+                                      const void* dy, float* dw, float* db, int B, int H, int W, int C, void* stream) {
+    NVAE_REQUIRE(is16(dtype) && scale && shift, "dwconv5_wgrad_pre: needs a 16-bit activation type and a coefficient table");
+    NVAE_REQUIRE(act == ACT_NONE || act == ACT_SWISH, "dwconv5_wgrad_pre: act %d unsupported", act);
+    DwPre pre{};
+    pre.on = 1; pre.act = act; pre.bn.scale = (float*)scale; pre.bn.shift = (float*)shift;
+    return dwconv5_wgrad_impl(dtype, x, dy, dw, db, B, H, W, C, stream, pre);
 }

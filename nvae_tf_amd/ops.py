@@ -70,6 +70,7 @@ CONV_PRE = os.environ.get("NVAE_CONV_PRE", "1")
 # 4.8 us of a finalize launch or the ~0 of a consumer that reads the accumulated slab itself, so off by default
 STATS_FIN = os.environ.get("NVAE_STATS_FIN", "0") != "0"
 FUSE_BN_BWD = os.environ.get("NVAE_BN_BWD_FUSE", "1") != "0"   # BN backward sums in the dgrad epilogue
+DW_PRE = os.environ.get("NVAE_DW_PRE", "1") != "0"           # BN(+Swish) in front of a depthwise conv applied in its LDS tile
 BN_BWD_SPLIT = os.environ.get("NVAE_BN_BWD_SPLIT", "0") != "0"  # unfused BN backward: reduce + self-finishing apply
 
 
@@ -449,20 +450,36 @@ def dwconv5(ctx: Ctx, x: Var, dw, want_stats: bool = False) -> Var:
     ps = ctx.ps
     x.uses += 1
     B, H, W, Cc = x.shape
-    xt = x.t
+    # a lazy BatchNorm(+Swish) input is applied inside the 16-bit ring kernels (to the halo tile in LDS, and again by
+    # the weight-gradient kernel): the normalised activation is never written
+    lazy_in = DW_PRE and ctx.dtype != torch.float32 and x.pre is not None and x.pre.mat is None
     y = Var(ctx.empty(x.shape))
     rows = L.load().nvae_dwconv5_stats_rows(ctx.dt, B, H, W, Cc) if (want_stats and ctx.training) else 0
+    slab = None
     if rows > 0:
         slab = ctx.zero_slab(rows, Cc)       # accumulated into with atomics
-        call("nvae_dwconv5_stats", ctx.dt, ptr(xt), ptr(ps.view(dw.w)), ptr(ps.view(dw.b)), ptr(y.t), B, H, W, Cc,
-             ptr(slab))
         y.stats = (slab, rows)
+    if lazy_in:
+        pre = x.pre
+        xt = x.raw
+        call("nvae_dwconv5_pre", ctx.dt, ptr(xt), C.byref(pre.bn_in()), pre.act, ptr(ps.view(dw.w)), ptr(ps.view(dw.b)),
+             ptr(y.t), B, H, W, Cc, ptr(slab))
     else:
-        call("nvae_dwconv5", ctx.dt, ptr(xt), ptr(ps.view(dw.w)), ptr(ps.view(dw.b)), ptr(y.t), B, H, W, Cc, 0, 0)
+        xt = x.t
+        if rows > 0:
+            call("nvae_dwconv5_stats", ctx.dt, ptr(xt), ptr(ps.view(dw.w)), ptr(ps.view(dw.b)), ptr(y.t), B, H, W, Cc,
+                 ptr(slab))
+        else:
+            call("nvae_dwconv5", ctx.dt, ptr(xt), ptr(ps.view(dw.w)), ptr(ps.view(dw.b)), ptr(y.t), B, H, W, Cc, 0, 0)
     if ctx.record:
         def bwd():
-            ctx.side_launch(lambda: call("nvae_dwconv5_wgrad", ctx.dt, ptr(xt), ptr(y.g), ptr(ps.grads) + dw.w.off * 4,
-                                         ptr(ps.grads) + dw.b.off * 4, B, H, W, Cc), y.g)
+            if lazy_in:
+                ctx.side_launch(lambda: call("nvae_dwconv5_wgrad_pre", ctx.dt, ptr(xt), pre.scale, pre.shift, pre.act,
+                                             ptr(y.g), ptr(ps.grads) + dw.w.off * 4, ptr(ps.grads) + dw.b.off * 4,
+                                             B, H, W, Cc), y.g)
+            else:
+                ctx.side_launch(lambda: call("nvae_dwconv5_wgrad", ctx.dt, ptr(xt), ptr(y.g), ptr(ps.grads) + dw.w.off * 4,
+                                             ptr(ps.grads) + dw.b.off * 4, B, H, W, Cc), y.g)
             g, acc = ctx.grad_of(x)
             call("nvae_dwconv5", ctx.dt, ptr(y.g), ptr(ps.view(dw.w)), None, ptr(g), B, H, W, Cc, 1, acc)
         ctx.tape.append(bwd)

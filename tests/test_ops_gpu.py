@@ -524,6 +524,58 @@ def test_dwconv5(lib, dev, dtype, B, H, W_, C_):
     assert rel_err(acc, 2 * gr[0]) < 2 * tol
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
+@pytest.mark.parametrize("B,H,C_,act", [(5, 4, 1536, 1), (3, 8, 96, 1), (2, 16, 192, 0), (40, 32, 64, 1)],
+                         ids=["4x4", "8x8", "16x16", "many-tiles"])
+def test_dwconv5_bn_prologue(lib, dev, monkeypatch, dtype, B, H, C_, act):
+    """BatchNorm(+Swish) -> depthwise 5x5 (decoder.py:125-131) with the BatchNorm applied inside the depthwise kernels
+    (nvae_dwconv5_pre / nvae_dwconv5_wgrad_pre: never materialised) against the same chain with a materialised
+    BatchNorm output: same rounding points, so outputs, statistics, every gradient and the published coefficient table /
+    moving statistics agree to f32 summation-order noise; and against the fp64 chain within the dtype's tolerance."""
+    from nvae_tf_amd import ops
+    from nvae_tf_amd.ops import Var
+    from nvae_tf_amd.params import ParamStore
+    g = torch.Generator().manual_seed(23)
+    x = torch.randn(B, H, H, C_, generator=g) * 1.5 + 0.3
+    dy = torch.randn(B, H, H, C_, generator=g)
+    res = {}
+    for mode in ("pre", "materialised"):
+        monkeypatch.setattr(ops, "DW_PRE", mode == "pre")
+        ps = ParamStore(seed=2)
+        bn, dw = ps.bn("bn", C_), ps.dw("dw", C_)
+        ps.finalize(dev, dtype, zero_pool_floats=1 << 18)
+        gg = torch.Generator().manual_seed(5)
+        ps.get("bn.gamma").copy_(torch.rand(C_, generator=gg) + 0.5); ps.get("bn.beta").copy_(torch.randn(C_, generator=gg) * 0.3)
+        ps.get("dw.b").copy_(torch.randn(C_, generator=gg))
+        ctx = make_ctx(ps, dtype)
+        xv = Var(x.to(dev, dtype))
+        h = ops.bn_act(ctx, xv, bn, act)
+        y = ops.dwconv5(ctx, h, dw, want_stats=True)
+        assert (h.pre.mat is None) == (mode == "pre")
+        y.g = dy.to(dev, dtype)
+        ctx.backward()
+        torch.cuda.synchronize()
+        res[mode] = dict(y=y.t.float(), stats=y.stats[0].float().sum(0), dx=xv.g.float(), dw=ps.get_grad("dw.w").clone(),
+                         db=ps.get_grad("dw.b").clone(), dgamma=ps.get_grad("bn.gamma").clone(),
+                         dbeta=ps.get_grad("bn.beta").clone(), rm=ps.get_state("bn.rm").clone(), rv=ps.get_state("bn.rv").clone())
+        if mode == "pre":
+            w64, b64 = ps.get("dw.w").cpu().double(), ps.get("dw.b").cpu().double()
+            g64, be64 = ps.get("bn.gamma").cpu().double(), ps.get("bn.beta").cpu().double()
+    a, b = res["pre"], res["materialised"]
+    for k in a:
+        assert rel_err(a[k], b[k]) < 1e-5, k
+    # fp64 chain
+    x64 = q(x, dtype).requires_grad_(True)
+    m = x64.mean((0, 1, 2)); v = x64.var((0, 1, 2), unbiased=False)
+    z = (x64 - m) / torch.sqrt(v + 1e-5) * g64 + be64
+    hz = z * torch.sigmoid(z) if act else z
+    yr = F.conv2d(F.pad(hz.permute(0, 3, 1, 2), (2, 2, 2, 2)), w64.permute(2, 0, 1).unsqueeze(1).contiguous(), b64,
+                  groups=C_).permute(0, 2, 3, 1)
+    gx, = torch.autograd.grad(yr, [x64], q(dy, dtype))
+    tol = TOL[dtype]
+    assert rel_err(a["y"], yr) < 2 * tol and rel_err(a["dx"], gx) < 4 * tol
+
+
 def _softclamp5(x):
     return 5.0 * torch.tanh(x / 5.0)
 
