@@ -875,7 +875,13 @@ static int launch_conv_gemm(const NvaeConvGeom* g, const void* src, const void* 
       else LAUNCH2F(BM_, BN_, WM_, WN_, ST_, BKC_, false, false) }
     // Large problems: 128-row tiles, 8 waves; N tile with the least padding (ties -> larger).
     // Small problems (few tiles): 64 x 64 tiles, 4 waves, so that the grid covers the chip.
-    switch ((g_force_tile && !be.x) ? g_force_tile : conv_tile_family(g)) {
+    int family = conv_tile_family(g);
+    // An operand prologue is redone by every N-tile that stages the element, so its cost follows the number of N-tiles:
+    // the short-K expand convs (256 -> 1536 at 4x4) run 64-wide tiles without it (7.9 us) and 128-wide ones with it
+    // (11.8 us against 16.5; tools/tune_wide.py).  The statistics slab is indexed modulo its row count, so a tile
+    // height other than conv_gemm_bm()'s stays correct (the in-kernel finalize counts M-tiles, so not with it).
+    if (use_pre && !sfin.counter && family == 7 && N >= 1024 && N % 128 == 0 && M % 128 == 0) family = 3;
+    switch ((g_force_tile && !be.x) ? g_force_tile : family) {
         case 1: LAUNCH2(256, 192, 4, 2, 2, 8) break;
         case 2: LAUNCH2(128, 192, 2, 4, 3, 8) break;
         case 3: LAUNCH2(128, 128, 2, 4, 3, 8) break;
