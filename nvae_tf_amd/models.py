@@ -346,6 +346,7 @@ class NVAE:
         self._prepare_weights_staged(spectral_norm and not self.tf_literal)
         ctx = Ctx(ps, self.dtype, training=not self.tf_literal, record=True,
                   side_stream=self._side if self.overlap_wgrad else None)
+        ctx.dw_pre = self.reducer is None
         self._bn_loss = ctx.zeros_f32(1)
         nb = len(ps.bn_loss_layers)
         if nb:

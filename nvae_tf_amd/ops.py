@@ -88,6 +88,11 @@ class Ctx:
         self.wgrad_q: List[tuple] = []      # MFMA conv weight gradients waiting to be launched in same-shape batches
         self.se_q: List[tuple] = []         # SE FC parameter gradients, likewise
         self.flush_every = int(os.environ.get("NVAE_WGRAD_FLUSH", "256"))
+        # BN(+Swish) -> depthwise 5x5 without materialising the activation: the forward kernel gets 4-7 us slower and
+        # saves a 10 us launch, the weight-gradient kernel (side stream) gets 7-15 us slower.  Worth it when the side
+        # stream runs under the main chain (single GPU: +0.3 %), not when every backward segment joins it (data
+        # parallel) - the model switches it off there.
+        self.dw_pre = True
         self.dtype = dtype
         self.dt = L.dtype_code(dtype)
         self.ve = 4 if dtype == torch.float32 else 8
@@ -452,7 +457,7 @@ def dwconv5(ctx: Ctx, x: Var, dw, want_stats: bool = False) -> Var:
     B, H, W, Cc = x.shape
     # a lazy BatchNorm(+Swish) input is applied inside the 16-bit ring kernels (to the halo tile in LDS, and again by
     # the weight-gradient kernel): the normalised activation is never written
-    lazy_in = DW_PRE and ctx.dtype != torch.float32 and x.pre is not None and x.pre.mat is None
+    lazy_in = DW_PRE and ctx.dw_pre and ctx.dtype != torch.float32 and x.pre is not None and x.pre.mat is None
     y = Var(ctx.empty(x.shape))
     rows = L.load().nvae_dwconv5_stats_rows(ctx.dt, B, H, W, Cc) if (want_stats and ctx.training) else 0
     slab = None
