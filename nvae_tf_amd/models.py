@@ -27,6 +27,7 @@ ADAMAX_B1, ADAMAX_B2, ADAMAX_EPS = 0.9, 0.999, 1e-7   # Keras Adamax defaults [3
 # single-GPU overlap of the step's HBM-bound bookkeeping with its launch-bound compute (both default on):
 # per-step scalars uploaded without a host sync: measured SLOWER (6 097-6 144 vs 6 211-6 225 images/s on one box) - with
 # the host running ahead, the next step's side-stream prologue competes with the tail of the current step
+CAPTURE_PRIORITY = os.environ.get("NVAE_CAPTURE_PRIORITY", "0") != "0"
 ASYNC_HYPER = os.environ.get("NVAE_ASYNC_HYPER", "0") != "0"
 OVERLAP_PREP = os.environ.get("NVAE_OVERLAP_PREP", "1") != "0"      # SN + weight copies of later modules on the side stream
 # Adamax of a finished backward segment on the side stream: measured SLOWER (21.1-21.3 vs 20.4 ms/step) - cutting the
@@ -532,6 +533,12 @@ class NVAE:
         g1, g3 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         # thread_local: a NCCL/RCCL watchdog thread may touch the HIP API while we capture
         kw = dict(pool=pool, capture_error_mode="thread_local")
+        if CAPTURE_PRIORITY:
+            # capture on a high-priority stream so that the main chain's kernel nodes outrank the side stream's
+            # weight-gradient nodes when both are runnable.  Measured SLOWER: 6 190-6 215 against 6 300-6 320 images/s
+            # (and 3 905 with the weight gradients flushed every 64), so off by default (NVAE_CAPTURE_PRIORITY=1)
+            lo, hi = torch.cuda.Stream.priority_range() if hasattr(torch.cuda.Stream, "priority_range") else (0, -1)
+            kw["stream"] = torch.cuda.Stream(device=self.device, priority=hi)
         with torch.cuda.graph(g1, **kw):
             ctx = self._seg_forward(self._static_x, None)
         if self._dp_segments():
