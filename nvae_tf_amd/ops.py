@@ -70,6 +70,7 @@ CONV_PRE = os.environ.get("NVAE_CONV_PRE", "1")
 # 4.8 us of a finalize launch or the ~0 of a consumer that reads the accumulated slab itself, so off by default
 STATS_FIN = os.environ.get("NVAE_STATS_FIN", "0") != "0"
 FUSE_BN_BWD = os.environ.get("NVAE_BN_BWD_FUSE", "1") != "0"   # BN backward sums in the dgrad epilogue
+WGRAD_ORDER = os.environ.get("NVAE_WGRAD_ORDER", "queue")     # queue | small_first | big_first (within one flush)
 DW_PRE = os.environ.get("NVAE_DW_PRE", "1") != "0"           # BN(+Swish) in front of a depthwise conv applied in its LDS tile
 BN_BWD_SPLIT = os.environ.get("NVAE_BN_BWD_SPLIT", "0") != "0"  # unfused BN backward: reduce + self-finishing apply
 
@@ -193,8 +194,13 @@ class Ctx:
         for item in self.wgrad_q:
             groups.setdefault(item[0], []).append(item)
         self.wgrad_q.clear()
-        lib = L.load()
-        for key, items in groups.items():
+        order = list(groups.items())
+        if WGRAD_ORDER != "queue":
+            # per-launch work of a group: pixels x K x N of one layer (x layers in the batch)
+            work = lambda kv: (kv[1][0][1].B * kv[1][0][1].Hout * kv[1][0][1].Wout * kv[1][0][1].KH * kv[1][0][1].KW
+                               * kv[1][0][1].Cin * kv[1][0][1].Cout)
+            order.sort(key=work, reverse=(WGRAD_ORDER == "big_first"))
+        for key, items in order:
             gw, dw_ld = items[0][1], key[1]
             for i0 in range(0, len(items), 32):
                 chunk = items[i0:i0 + 32]
