@@ -1,6 +1,6 @@
 """Diagnostic: C2 architecture forward parity (f32 HIP vs fp64 oracle) at several batch sizes: loss terms per group."""
 import sys, os
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch
 import test_model_gpu as T

@@ -1,6 +1,6 @@
 """Diagnostic: C2 train-step parity at batch 8 (f32 HIP vs fp64 oracle): loss, KL groups, gradient cosine, worst tensors."""
 import sys, os
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch
 import test_model_gpu as T

@@ -354,7 +354,7 @@ def test_c2_architecture_parity(lib, dev, batch):
     62 225 021 parameters, 15 latent groups): f32 HIP path vs the fp64 oracle - losses, all 15 per-group KLs,
     balancing coefficients, per-tensor gradients and the direction of the whole 62 M-element gradient.
 
-    Conditioning (measured, tools/diag_c2b.py and the PyTorch-CPU f32 run of the oracle itself): at this random
+    Conditioning (measured, tests/diag/diag_c2b.py and the PyTorch-CPU f32 run of the oracle itself): at this random
     initialisation the 330-layer network amplifies f32 rounding by ~1e4, more with the batch size - the gradient norm
     is 6.9e6 at batch 2, 2.2e7 at 4, 1.3e8 at 8.  At batch 8 the f32 PyTorch run of the ORACLE is 4.6e-4 off the
     fp64 loss (and moves by +-3 nats = 1.5e-3 under 1-ulp perturbations of the weights or a different thread count),
