@@ -665,8 +665,14 @@ def bn_act(ctx: Ctx, x: Var, bn, act: int = L.ACT_NONE, lazy: bool = True) -> Va
 # ------------------------------------------------------------------------------------------
 # Squeeze-Excitation + residual
 # ------------------------------------------------------------------------------------------
-def _se_fused_ok(Cc: int, Hd: int) -> bool:
-    return SE_FUSED and Cc & (Cc - 1) == 0 and 8 <= Cc <= 2048 and Hd <= 128
+SE_FUSED_MIN_B = int(os.environ.get("NVAE_SE_FUSED_MIN_B", "0"))
+
+
+def _se_fused_ok(Cc: int, Hd: int, B: int) -> bool:
+    # a fused SE workgroup owns whole images, so the launch has at most B workgroups.  Falling back to the strip-structured
+    # three-kernel path for small batches (NVAE_SE_FUSED_MIN_B) was measured on the side workloads: C1 (batch 32) 3 %
+    # slower, C4 (batch 64) equal, C5 (batch 32) 2 % faster - no clear winner, so the fused kernels stay the default
+    return SE_FUSED and Cc & (Cc - 1) == 0 and 8 <= Cc <= 2048 and Hd <= 128 and B >= SE_FUSED_MIN_B
 
 
 def se_residual(ctx: Ctx, x: Var, se, skip: Var, skip_scale: float, branch_scale: float, stats_bn=None) -> Var:
@@ -682,7 +688,7 @@ def se_residual(ctx: Ctx, x: Var, se, skip: Var, skip_scale: float, branch_scale
     gate = ctx.empty((B, Cc), torch.float32)
     hidden = ctx.empty((B, Hd), torch.float32)
     w1, b1, w2, b2 = (ptr(ps.view(p)) for p in (se.w1, se.b1, se.w2, se.b2))
-    fused = _se_fused_ok(Cc, Hd)
+    fused = _se_fused_ok(Cc, Hd, B)
     lazy_in = fused and x.pre is not None and x.pre.act == L.ACT_NONE and x.pre.mat is None
     if lazy_in:
         bn_in = C.byref(x.pre.bn_in())          # the kernel finishes the statistics itself if nobody has yet

@@ -385,14 +385,17 @@ def test_fused_bn_chain(lib, dev, dtype, case, mode, monkeypatch):
 @pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16", "f16"])
 @pytest.mark.parametrize("shape", [(6, 4, 4, 256), (3, 8, 8, 72), (2, 16, 16, 64), (130, 4, 4, 128), (2, 32, 32, 32)])
 @pytest.mark.parametrize("lazy", [False, True], ids=["materialised", "lazy"])
-def test_fused_bn_se_chain(lib, dev, dtype, shape, lazy):
+@pytest.mark.parametrize("se_path", ["fused", "strips"])
+def test_fused_bn_se_chain(lib, dev, dtype, shape, lazy, se_path, monkeypatch):
     """BN -> SE + residual -> BN: the SE kernel emits the next BatchNorm's statistics, its backward apply
     reduces the previous BatchNorm's backward sums; both BatchNorms use the finalize-in-apply passes.
     lazy: the first BatchNorm is applied inside the fused SE kernels (forward and backward) from its
     coefficient table and its output is never materialised (nor rounded to the activation dtype).
     (130 images: more than the 128 rows of the fused kernels' statistics slab -> two images per workgroup;
-    72 channels: not a power of two -> the unfused launch sequence.)"""
+    72 channels: not a power of two -> the unfused launch sequence.)  se_path: the one-launch kernels or the
+    strip-structured three-kernel path (the default below ~100 images), both at every shape."""
     from nvae_tf_amd import ops
+    monkeypatch.setattr(ops, "SE_FUSED_MIN_B", 0 if se_path == "fused" else 10 ** 9)
     from nvae_tf_amd.ops import Var
     from nvae_tf_amd.params import ParamStore
     g = torch.Generator().manual_seed(31)
@@ -412,7 +415,7 @@ def test_fused_bn_se_chain(lib, dev, dtype, shape, lazy):
         m, v = t.mean((0, 1, 2)), t.var((0, 1, 2), unbiased=False)
         return (t - m) * torch.rsqrt(v + 1e-5) * ga + be
     a = bn_ref(x64, P["bn1.gamma"], P["bn1.beta"])
-    really_lazy = lazy and C_ & (C_ - 1) == 0
+    really_lazy = lazy and C_ & (C_ - 1) == 0 and se_path == "fused"
     aq = a if really_lazy else q(a.detach().float(), dtype) + (a - a.detach())
     gate = torch.sigmoid(torch.relu(aq.mean((1, 2)) @ P["se.w1"] + P["se.b1"]) @ P["se.w2"] + P["se.b2"])
     r = 0.1 * s64 + aq * gate[:, None, None, :]
@@ -445,8 +448,12 @@ def test_fused_bn_se_chain(lib, dev, dtype, shape, lazy):
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16", "f16"])
 @pytest.mark.parametrize("shape,ss,bs", [((3, 8, 8, 128), 0.1, 1.0), ((4, 4, 4, 256), 1.0, 0.1), ((2, 32, 32, 32), 1.0, 0.1)])
-def test_se_residual(lib, dev, dtype, shape, ss, bs):
+@pytest.mark.parametrize("se_path", ["fused", "strips"])
+def test_se_residual(lib, dev, dtype, shape, ss, bs, se_path, monkeypatch):
     from nvae_tf_amd import ops
+    # the one-launch kernels (whole images per workgroup) are the default from ~100 images up, the strip-structured
+    # three-kernel path below that: both at every shape here
+    monkeypatch.setattr(ops, "SE_FUSED_MIN_B", 0 if se_path == "fused" else 10 ** 9)
     from nvae_tf_amd.ops import Var
     from nvae_tf_amd.params import ParamStore
     g = torch.Generator().manual_seed(13)
