@@ -153,11 +153,13 @@ def test_rgb_inference_sampling_and_graph(lib, dev):
     assert math.isfinite(float(o1["loss"]))
 
 
-@pytest.mark.parametrize("name,B", [("cifar10", 8), ("celeba64", 4)])
+@pytest.mark.parametrize("name,B", [("cifar10", 8)])
 def test_baseline_rgb_configs(lib, dev, name, B):
-    """BASELINE.json configs[3] (CIFAR-10, 30 groups) and configs[4] (CelebA-64, 40 groups) at full
-    width and depth, reduced batch: parameter count against the oracle's constructor, one bf16
-    training step with finite losses, KL-per-group of the right shape, gradients flowing to the stem."""
+    """BASELINE.json configs[3] (CIFAR-10, 30 groups) at full width and depth, reduced batch: parameter count against
+    the oracle's constructor, one bf16 training step with finite losses, KL-per-group of the right shape, gradients
+    flowing to the stem.  (configs[4], CelebA-64 with 40 groups: the same check costs 25 s of oracle construction;
+    its parameter total, verified this way in round 1, is asserted in tests/test_fullsize_gpu.py next to the
+    full-batch properties.)"""
     from nvae_tf_amd import configs
     from oracle.nvae_oracle import OracleConfig, OracleNVAE, synthetic_rgb_batch
     c = configs.CONFIGS[name]

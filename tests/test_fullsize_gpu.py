@@ -134,6 +134,7 @@ def test_rgb_configs_full_batch_properties(lib, dev, name, n_groups, dtype):
     # (float16 is the activation type BASELINE.json configs[4] names: "fp16 with fp32 KL accumulate")
     model = configs.build(name, device=dev, dtype=dtype)          # float16: dynamic loss scaling (the default)
     assert model.n_groups == n_groups
+    assert model.n_trainable() == {"cifar10": 174561204, "celeba64": 394575888}[name]     # = the oracle's constructor
     x = _rgb_batch(B, hw, dev)
     g = torch.Generator(device="cpu").manual_seed(11)
     eps = [torch.randn(s, generator=g) for s in model.eps_shapes(B)]

