@@ -159,6 +159,23 @@ __device__ __forceinline__ void conv_epilogue(f32x4 (&acc)[BM / WM / 16][BN / WN
             s1[e] = 0; s2[e] = 0;
         }
         const T* bx = (const T*)be.x;
+        // 16-bit tensors: every x vector this lane will need (MI slabs x RPL rows) is requested NOW, before the slabs
+        // are staged through LDS - issued inside the loop, each slab exposed one global-load latency
+        constexpr int RPL = (16 + RPP - 1) / RPP;
+        uint4 xq[sizeof(T) == 2 ? MI : 1][sizeof(T) == 2 ? RPL : 1];
+        if constexpr (sizeof(T) == 2) {
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int k = 0; k < RPL; ++k) {
+                    const int row = rl + k * RPP;
+                    xq[i][k] = make_uint4(0u, 0u, 0u, 0u);
+                    if (act_lane && nval && row < 16) {
+                        const long m = row_m(wm * (BM / WM) + i * 16 + row);
+                        if (m >= 0) xq[i][k] = *(const uint4*)(bx + m * be.x_ld + n0);
+                    }
+                }
+        }
         __syncthreads();
         float* st = lds_f + wave * (16 * SROW);
 #pragma unroll
@@ -169,7 +186,10 @@ __device__ __forceinline__ void conv_epilogue(f32x4 (&acc)[BM / WM / 16][BN / WN
                 for (int r = 0; r < 4; ++r) st[(fq * 4 + r) * SROW + j * 16 + fr] = acc[i][j][r];
             __syncthreads();
             if (act_lane && nval)
-                for (int row = rl; row < 16; row += RPP) {
+#pragma unroll
+                for (int k = 0; k < RPL; ++k) {
+                    const int row = rl + k * RPP;
+                    if (row >= 16) continue;
                     const long m = row_m(wm * (BM / WM) + i * 16 + row);
                     if (m < 0) continue;
                     float o[8], xv[8];
@@ -186,7 +206,8 @@ __device__ __forceinline__ void conv_epilogue(f32x4 (&acc)[BM / WM / 16][BN / WN
                         for (int e = 0; e < 8; ++e) o[e] += rr[e];
                     }
                     V8<T>::st((T*)out + m * g.out_ld + n0, o);
-                    V8<T>::ld(bx + m * be.x_ld + n0, xv);
+                    if constexpr (sizeof(T) == 2) unpack8<T>(xq[i][k], xv);
+                    else V8<T>::ld(bx + m * be.x_ld + n0, xv);
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
                         float dpre = o[e];
