@@ -246,6 +246,28 @@ __device__ __forceinline__ void conv_epilogue(f32x4 (&acc)[BM / WM / 16][BN / WN
         return;
     }
     if (vec_epi) {
+        // 16-bit residual (skip connections, accumulating data gradients): all of this lane's residual vectors are
+        // requested before the slabs are staged, like the x vectors of the BN-backward epilogue above
+        constexpr int VPL = (16 * VPR + 63) / 64;
+        uint4 rq[sizeof(T) == 2 ? MI : 1][sizeof(T) == 2 ? VPL : 1];
+        const bool rpre = sizeof(T) == 2 && residual != nullptr;
+        if constexpr (sizeof(T) == 2) {
+            if (rpre) {
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int k = 0; k < VPL; ++k) {
+                        const int v = lane + 64 * k;
+                        rq[i][k] = make_uint4(0u, 0u, 0u, 0u);
+                        if (v < 16 * VPR) {
+                            const int row = v / VPR, c8 = v - row * VPR;
+                            const long m = row_m(wm * (BM / WM) + i * 16 + row);
+                            const int n0 = bn * BN + wn * WCOLS + c8 * 8;
+                            if (m >= 0 && n0 + 8 <= N) rq[i][k] = *(const uint4*)(residual + m * g.res_ld + n0);
+                        }
+                    }
+            }
+        }
         __syncthreads();
         float* st = lds_f + wave * (16 * SROW);
 #pragma unroll
@@ -255,7 +277,10 @@ __device__ __forceinline__ void conv_epilogue(f32x4 (&acc)[BM / WM / 16][BN / WN
 #pragma unroll
                 for (int r = 0; r < 4; ++r) st[(fq * 4 + r) * SROW + j * 16 + fr] = acc[i][j][r];
             __syncthreads();
-            for (int v = lane; v < 16 * VPR; v += 64) {
+#pragma unroll
+            for (int k = 0; k < VPL; ++k) {
+                const int v = lane + 64 * k;
+                if (v >= 16 * VPR) continue;
                 const int row = v / VPR, c8 = v - row * VPR;
                 const long m = row_m(wm * (BM / WM) + i * 16 + row);
                 const int n0 = bn * BN + wn * WCOLS + c8 * 8;
@@ -270,7 +295,8 @@ __device__ __forceinline__ void conv_epilogue(f32x4 (&acc)[BM / WM / 16][BN / WN
                     }
                     if (residual) {
                         float rr[8];
-                        V8<T>::ld(residual + m * g.res_ld + n0, rr);
+                        if constexpr (sizeof(T) == 2) unpack8<T>(rq[i][k], rr);
+                        else V8<T>::ld(residual + m * g.res_ld + n0, rr);
 #pragma unroll
                         for (int e = 0; e < 8; ++e) o[e] += rr[e];
                     }
