@@ -20,6 +20,7 @@
 #ifndef NVAE_HIP_H
 #define NVAE_HIP_H
 
+#include <stddef.h>
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -42,7 +43,7 @@ extern "C" {
 
 /* Bumped whenever an entry point is added or a signature changes; the Python binding (nvae_tf_amd/_lib.py
  * ABI_VERSION) refuses to load a library that reports another value. */
-#define NVAE_ABI_VERSION 3
+#define NVAE_ABI_VERSION 4
 
 const char* nvae_last_error(void);
 int nvae_abi_version(void);
@@ -119,6 +120,24 @@ int nvae_conv_gemm_pre_max_cin(int dtype, const NvaeConvGeom* g);
 /* Tuning hook (tools/tune_conv.py): 0 = the launcher's own tile choice (default), 1..7 = force one tile family of
  * the generic implicit-GEMM kernel for plain launches.  Process-wide; not for production use.       */
 int nvae_conv_gemm_force_tile(int tile);
+/* Split-K workspace of the implicit-GEMM kernel.  The small-M layers with a long K loop (the 3x3 convs of
+ * EncodingResidualCell at 4x4 / 8x8, encoder.py:92-98, and the K = 6*C 1x1 convs of GenerativeResidualCell,
+ * decoder.py:126-134, forward and data gradient) are launched as S workgroups per output tile, each over 1/S of K:
+ * the f32 partial tiles go through `slab` (write-through stores), the last workgroup to arrive at the tile's
+ * counter sums them in slice order (bit-identical whatever the arrival order) and runs the usual epilogue.
+ *   slab: >= bytes of device memory, 16-B aligned; counters: n_counters ints, ZEROED once by the caller (the
+ *   kernels leave them zero).  Launches that share a workspace must be stream-ordered (one workspace per stream
+ *   that issues convolutions).  NULL / NULL: no launch is split.  Process-wide setting.                     */
+int nvae_conv_set_workspace(void* slab, size_t bytes, int* counters, int n_counters);
+/* Tuning hook (tools/mb_smallconv.py): 0 = the launcher's own choice, S >= 1 = force S K-slices per tile. */
+int nvae_conv_gemm_force_split(int S);
+/* 1 if nvae_conv_gemm* runs this geometry on the whole-image 3x3 kernel (k_conv_img: 16-bit activations, 3x3 'same'
+ * stride-1 convs on 4x4 / 8x8 images with 128 or 256 input channels - EncodingResidualCell at the two latent scales,
+ * encoder.py:92-98, forward and data gradient).  Its NvaeConvPre prologue transforms the staged tile once per
+ * workgroup, so the host uses the prologue for these convs even behind a Swish.                              */
+int nvae_conv_img_ok(int dtype, const NvaeConvGeom* g);
+/* Tuning / test hook: 0 = never select the whole-image kernel (the generic implicit GEMM runs instead). */
+int nvae_conv_img_enable(int on);
 /* nvae_conv_gemm used as the DATA GRADIENT of a conv whose input was y = act(BN(x)) (the BNSwishConv /
  * ConvBNSwish pairs, encoder.py:91-98, decoder.py:125-135, postprocess.py:84-107): `out` receives dy
  * as usual and the epilogue additionally reduces dpre = dy * act'(scale*x + shift) against the same

@@ -13,7 +13,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libnvae_hip.so")
 
-ABI_VERSION = 3          # must equal nvae_abi_version() of the loaded library (include/nvae_hip.h NVAE_ABI_VERSION)
+ABI_VERSION = 4          # must equal nvae_abi_version() of the loaded library (include/nvae_hip.h NVAE_ABI_VERSION)
 F32, BF16, F16 = 0, 1, 2
 ACT_NONE, ACT_SWISH, ACT_ELU = 0, 1, 2
 OP_AFFINE, OP_SWISH, OP_ELU = 0, 1, 2
@@ -67,6 +67,10 @@ _SIGS = {
     "nvae_conv_gemm_ex": [_i, _G, _p, _p, _i, _p, _p, _p, _i, _p, _p, _p],
     "nvae_conv_gemm_pre_max_cin": None,
     "nvae_conv_gemm_force_tile": None,
+    "nvae_conv_gemm_force_split": None,
+    "nvae_conv_set_workspace": None,
+    "nvae_conv_img_ok": None,
+    "nvae_conv_img_enable": None,
     "nvae_conv_gemm_bnbwd": [_i, _p, _p, _p, _i, _p, _p, _p, _p],
     "nvae_conv_wgrad_scratch": None,
     "nvae_conv_wgrad_scratch_n": None,
@@ -167,6 +171,14 @@ def load():
     lib.nvae_conv_gemm_stats_rows.argtypes = [_i, _G]
     lib.nvae_conv_gemm_force_tile.restype = C.c_int
     lib.nvae_conv_gemm_force_tile.argtypes = [_i]
+    lib.nvae_conv_gemm_force_split.restype = C.c_int
+    lib.nvae_conv_gemm_force_split.argtypes = [_i]
+    lib.nvae_conv_set_workspace.restype = C.c_int
+    lib.nvae_conv_set_workspace.argtypes = [_p, C.c_size_t, _p, _i]
+    lib.nvae_conv_img_ok.restype = C.c_int
+    lib.nvae_conv_img_ok.argtypes = [_i, _G]
+    lib.nvae_conv_img_enable.restype = C.c_int
+    lib.nvae_conv_img_enable.argtypes = [_i]
     lib.nvae_conv_gemm_pre_max_cin.restype = C.c_int
     lib.nvae_conv_gemm_pre_max_cin.argtypes = [_i, _G]
     lib.nvae_conv_wgrad_scratch.restype = C.c_long

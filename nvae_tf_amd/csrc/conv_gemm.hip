@@ -53,6 +53,15 @@ struct ConvPre {
     void* act_out; int act_ld;
 };
 
+// Split-K of k_conv_gemm2 (small-M layers whose K loop is long: the 3x3 convs and the 6x-wide 1x1 convs of the
+// 4x4 / 8x8 towers): S workgroups per output tile, each `steps` ring steps of the K loop.  slab / counter: the
+// workspace registered with nvae_conv_set_workspace (launches that share it must be stream-ordered).
+struct ConvSplitK {
+    int S, steps;
+    float* slab;                // [tiles][S][BM*BN] f32 partial tiles, lane-linear
+    int* counter;               // [tiles], zero at rest
+};
+
 template <typename T> __device__ __forceinline__ uint4 pre_chunk(uint4 raw, const float* sc, const float* sh, int act) {
     if constexpr (sizeof(T) == 2) {
         float v[8];
@@ -355,7 +364,7 @@ __global__ __launch_bounds__(WM* WN * 64) void k_conv_gemm2(
     NvaeConvGeom g, const T* __restrict__ src, const T* __restrict__ wT, int w_ld,
     const float* __restrict__ bias, const T* residual, void* out, int out_f32, int M, int K, int n_tiles,
     int total_tiles, FastDiv fd_hw, FastDiv fd_w, const uint4* __restrict__ zeros, float* stats,
-    int vec_epi, ConvBnBwd be, ConvPre pre, BnFinArgs sfin) {
+    int vec_epi, ConvBnBwd be, ConvPre pre, BnFinArgs sfin, ConvSplitK sk) {
     constexpr int NT = WM * WN * 64;
     constexpr int VE = Tr<T>::VE;
     constexpr int BKE = BKC * VE;                  // K elements per ring step (BKC 16-B chunks per row)
@@ -369,21 +378,25 @@ __global__ __launch_bounds__(WM* WN * 64) void k_conv_gemm2(
     static_assert(STAGES * STAGE * 16 >= WM * BN * 2 * 8, "stats scratch must fit in the ring");
     static_assert(!BNBWD || STAGES * STAGE * 16 >= WM * ((64 / (BN / WN / 8)) < 16 ? (64 / (BN / WN / 8)) : 16) * BN * 2 * (int)sizeof(typename StatT<T>::type),
                   "BN-backward scratch must fit in the ring");
-    static_assert(STAGES >= 2 && STAGES <= 4, "ring depth");
+    static_assert(STAGES >= 2 && STAGES <= 6, "ring depth");
     __shared__ uint4 lds[STAGES * STAGE];
     __shared__ __attribute__((aligned(16))) float pre_tab[PRE ? 2 * PRE_MAXC : 4];   // [scale | shift] of the prologue
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave - wm * WN;
-    const int tile = xcd_remap(blockIdx.x, total_tiles);
+    // split-K (sk.S > 1): the S workgroups of a tile are neighbours in the remapped numbering (one XCD), each takes
+    // `sk.steps` ring steps of the K loop; see the hand-off after the loop
+    const int wg = xcd_remap(blockIdx.x, total_tiles * sk.S);
+    const int tile = wg / sk.S, ks = wg - tile * sk.S;
     const int bm = tile / n_tiles, bn = tile - bm * n_tiles;
     const int N = g.Cout;
     const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)lds;
+    const int t_begin = ks * sk.steps;             // first ring step of this workgroup
 
     // ---- per-thread gather state: chunk q = tid + NT*i  ->  row q / BKC, physical slot q % BKC
     const int row0 = tid / BKC;
-    const int kc = ((tid % BKC) ^ swz_row<BKC>(row0)) * VE;
+    const int kc = t_begin * BKE + ((tid % BKC) ^ swz_row<BKC>(row0)) * VE;
     int tap = kc / g.Cin;
     int ci = kc - tap * g.Cin;
     int kh = tap / g.KW, kw = tap - kh * g.KW;
@@ -455,23 +468,27 @@ __global__ __launch_bounds__(WM* WN * 64) void k_conv_gemm2(
         for (int c = tid; c < g.Cin; c += NT) bn_coef<sizeof(T) == 4>(pre.bn, g.Cin, c, blockIdx.x == 0, pre_tab[c], pre_tab[PRE_MAXC + c]);
         __syncthreads();
     }
-    const int nk = (K + BKE - 1) / BKE;
+    const int nk_all = (K + BKE - 1) / BKE;
+    const int nk = nk_all - t_begin < sk.steps ? nk_all - t_begin : sk.steps;
     const int fr = lane & 15, fq = lane >> 4;
     issue(0);
-    if (STAGES >= 3 && nk > 1) issue(1);
-    if (STAGES >= 4 && nk > 2) issue(2);
+#pragma unroll
+    for (int q = 1; q < STAGES - 1; ++q)
+        if (nk > q) issue(q);
     int cur = 0;
     for (int t = 0; t < nk; ++t) {
         // stage t must have landed; up to STAGES-2 younger stages may stay in flight
         const int younger = nk - 1 - t;
-        if (STAGES >= 4 && younger >= 2) wait_vmcnt<2 * NLOAD>();
+        if (STAGES >= 6 && younger >= 4) wait_vmcnt<4 * NLOAD>();
+        else if (STAGES >= 5 && younger >= 3) wait_vmcnt<3 * NLOAD>();
+        else if (STAGES >= 4 && younger >= 2) wait_vmcnt<2 * NLOAD>();
         else if (STAGES >= 3 && younger >= 1) wait_vmcnt<NLOAD>();
         else wait_vmcnt<0>();
         if constexpr (PRE) {
             // this thread's own A chunks of stage t are in LDS (its DMA, its vmcnt): normalise + activate them in
             // place; padding / out-of-range chunks stay zero.  The barrier below publishes them with the rest.
             const bool kval = p_kabs < K;
-            const bool my_turn = pre.act_out && (t % n_tiles) == bn && p_kh == g.pad_t && p_kw == g.pad_l;
+            const bool my_turn = pre.act_out && ((t_begin + t) % n_tiles) == bn && p_kh == g.pad_t && p_kw == g.pad_l;
 #pragma unroll
             for (int i = 0; i < ACH; ++i) {
                 const int hc = hb[i] + p_kh, wc = wb[i] + p_kw;
@@ -547,6 +564,69 @@ __global__ __launch_bounds__(WM* WN * 64) void k_conv_gemm2(
         cur = cur == STAGES - 1 ? 0 : cur + 1;
     }
 
+    // (big tiles are never split: their slab registers would spill in the common path)
+    constexpr int SPLIT_QC = MI * NI <= 2 ? 4 : 2;            // slabs requested per round trip by the reducer
+    if constexpr (MI * NI <= 4) if (sk.S > 1) {
+        // Split-K hand-off (cdna guide, "Projection GEMM at M = 256" item 2, the sc1 form): every workgroup writes its
+        // f32 partial tile lane-linearly (accumulator (i, j) of thread tid at [(i*NI + j)*NT + tid], 16 B per lane:
+        // whole lines, no layout work) with write-through stores, waits for them, and takes a ticket on the tile's
+        // counter; the one that draws S - 1 reads the other slabs with sc1 loads and runs the epilogue.  The sum is
+        // formed in slice order whoever arrives last (own slice from registers), so the result does not depend on
+        // the arrival order.  Counters are zero at rest: the last arriver resets its tile's.
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(sk.slab + (long)tile * sk.S * (BM * BN)), 0, sk.S * BM * BN * 4, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(bn_u4, acc[i][j]), rs,
+                                                       ((ks * MI * NI + i * NI + j) * NT + tid) * 16, 0, 16 /* sc1 */);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        int* flag = (int*)lds;                       // (the ring is no longer read)
+        if (tid == 0) {
+            const int old = atomicAdd(sk.counter + tile, 1);
+            if (old == sk.S - 1) atomicExch(sk.counter + tile, 0);
+            *flag = old;
+        }
+        __syncthreads();
+        const bool last = *flag == sk.S - 1;
+        __syncthreads();                             // everybody has read the flag before the epilogue reuses the ring
+        if (!last) return;
+        // ordered sum over the slices, four slabs requested per round trip; no branch around a load (a slice index
+        // past the end, or the own slice, is loaded anyway and not used): hipcc would wait for each load separately
+        f32x4 own[MI][NI];
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j) own[i][j] = acc[i][j];
+        for (int q0 = 0; q0 < sk.S; q0 += SPLIT_QC) {
+            bn_u4 v[SPLIT_QC][MI][NI];
+#pragma unroll
+            for (int u = 0; u < SPLIT_QC; ++u) {
+                const int q = q0 + u < sk.S ? q0 + u : sk.S - 1;
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NI; ++j)
+                        v[u][i][j] = __builtin_amdgcn_raw_buffer_load_b128(rs, ((q * MI * NI + i * NI + j) * NT + tid) * 16, 0, 16 /* sc1 */);
+            }
+#pragma unroll
+            for (int u = 0; u < SPLIT_QC; ++u) {
+                const int q = q0 + u;
+                if (q < sk.S) {
+#pragma unroll
+                    for (int i = 0; i < MI; ++i)
+#pragma unroll
+                        for (int j = 0; j < NI; ++j) {
+                            const f32x4 val = q == ks ? own[i][j] : __builtin_bit_cast(f32x4, v[u][i][j]);
+                            if (q == 0) acc[i][j] = val;
+                            else acc[i][j] += val;
+                        }
+                }
+            }
+        }
+    }
     int ticket = 0;
     conv_epilogue<T, BM, BN, WM, WN, BNBWD>(acc, (float*)lds, g, bias, residual, out, out_f32, bm, bn, stats, vec_epi,
                                             [&](int r) -> long { int m = bm * BM + r; return m < M ? (long)m : -1L; }, be,
@@ -708,14 +788,23 @@ __global__ __launch_bounds__(WM * 128) void k_conv_halo(
     if (lag) {
         prefetch(0, 0, 0);
         wait_vmcnt<0>();
+        if constexpr (PRE) {
+            // the lagging waves' share of chunk 0's halo must be normalised BEFORE this barrier: it pairs with the
+            // leading waves' barrier R(0), after which they read the halo for tap 0
+#pragma unroll
+            for (int i = 0; i < A_PASSES; ++i) pre_pass(0, i);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
         __builtin_amdgcn_s_barrier();
     }
     for (int s = 0; s < S; ++s) {
         wait_vmcnt<0>();
         if constexpr (PRE) {
             if (s == 0) {
+                if (!lag) {
 #pragma unroll
-                for (int i = 0; i < A_PASSES; ++i) pre_pass(0, i);
+                    for (int i = 0; i < A_PASSES; ++i) pre_pass(0, i);
+                }
             } else if (tap >= 1 && tap <= A_PASSES && cc + 1 < ncc) {
                 // the pass issued one step ago (tap - 1) for the NEXT chunk has landed; its buffer is not read
                 // before chunk cc + 1 starts
@@ -823,6 +912,160 @@ __global__ __launch_bounds__(WM * 128) void k_conv_halo(
     }
 }
 
+// =========================================================================================
+// k_conv_img: 3 x 3, stride 1, 'same' convolutions on WHOLE small images (4 x 4 or 8 x 8) -- the two convs of every
+// EncodingResidualCell of the 4x4 / 8x8 towers (encoder.py:92-98) and their data gradients, 120 launches per C2 step.
+//   Measured (tools/mb_smallconv.py, round 3): k_conv_gemm2 on these shapes is bound by the bytes a CU can pull through
+//   its L1 (~50 GB/s per CU whatever the ring depth, tile or K split: 32 x 64 tiles stage 442 KB per workgroup for the
+//   256 -> 256 conv at 4x4, 12.8 us; split-K moves the cost into its slab hand-off).  An im2col gather fetches every
+//   activation nine times.  Here the M-tile is 128 output pixels = 8 (4x4) or 2 (8x8) WHOLE images: their activations
+//   (128 x Cin) are DMA'd into LDS once and every tap reads its shifted window from there (a lane whose source pixel
+//   lies outside the image contributes zeros); with a 16-column N-tile a workgroup stages 64 + 72 KB for the same conv
+//   (3.2x fewer bytes) and the launch still has 256 workgroups.  K order is (64-channel chunk, tap), so the first
+//   chunk's MFMAs start when a quarter of the operands has landed.
+//   LDS: A [Cin/64][128 rows][8 x 16 B], B [Cin/64][9 taps][16 cols][8 x 16 B], slot = chunk ^ (row & 7) as in
+//   k_conv_halo (conflict-free at any row shift).  One wave = 16 pixels x 16 columns, one accumulator tile.
+//   The BatchNorm(+Swish) in front of the conv is applied to the staged tile ONCE per workgroup (ConvPre): unlike the
+//   im2col kernels' prologue (redone per tap) that costs 64 elements per thread, so the apply launch disappears.
+// =========================================================================================
+template <typename T, int HW, int CIN, bool BNBWD, bool PRE>
+__global__ __launch_bounds__(512) void k_conv_img(
+    NvaeConvGeom g, const T* __restrict__ src, const T* __restrict__ wT, int w_ld,
+    const float* __restrict__ bias, const T* residual, void* out, int out_f32, int M, int n_tiles, int total_tiles,
+    const uint4* __restrict__ zeros, float* stats, int vec_epi, ConvBnBwd be, ConvPre pre, BnFinArgs sfin) {
+    static_assert(sizeof(T) == 2, "16-bit activations only");
+    constexpr int BM = 128, BN = 16, NT = 512, P = HW * HW;
+    constexpr int NCC = CIN / 64;                       // 64-channel chunks
+    constexpr int A_CC = BM * 8, B_CC = 9 * BN * 8;     // 16-B chunks per channel chunk: 1024, 1152
+    constexpr int B_MAIN = 1024, B_LEFT = B_CC - B_MAIN;   // per chunk: 2 per thread + 128 left over
+    constexpr int LEFT = NCC * B_LEFT;                  // <= 512: one DMA of (some of) the waves, issued first
+    static_assert(CIN % 64 == 0 && LEFT <= NT && B_LEFT == 128, "channel count");
+    __shared__ uint4 lds[NCC * (A_CC + B_CC)];
+    __shared__ __attribute__((aligned(16))) float pre_tab[PRE ? 2 * CIN : 4];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tile = xcd_remap(blockIdx.x, total_tiles);
+    const int bm = tile / n_tiles, bn = tile - bm * n_tiles;
+    const int N = g.Cout;
+    const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)lds;
+    const unsigned b_base = lds_base + (unsigned)(NCC * A_CC) * 16u;
+
+    // ---- this thread's DMA sources.  A: chunk q = tid + 512*i of a channel chunk -> row q >> 3, slot q & 7
+    const int phys = tid & 7;
+    const T* a_src[2];
+    bool a_ok[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = (tid >> 3) + 64 * i;
+        const long m = (long)bm * BM + row;
+        a_ok[i] = m < M;
+        a_src[i] = src + (a_ok[i] ? m : 0) * g.in_ld + ((phys ^ (row & 7)) << 3);
+    }
+    // B main part: chunk q = tid + 512*i (< 1024) of a channel chunk -> (tap, col) = q >> 3, slot q & 7
+    const T* b_src[2];
+    bool b_ok[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int rc = (tid >> 3) + 64 * i;              // tap * 16 + col
+        const int tap = rc >> 4, col = rc & 15;
+        const int n = bn * BN + col;
+        b_ok[i] = n < N;
+        b_src[i] = wT + (long)(b_ok[i] ? n : 0) * w_ld + tap * CIN + ((phys ^ (col & 7)) << 3);
+    }
+    // B left-over: the last 128 chunks (tap 8) of every channel chunk, one DMA per thread of the first LEFT threads
+    if (wave * 64 < LEFT) {
+        const int cc = wave >> 1, q = B_MAIN + (wave & 1) * 64 + lane;        // (B_LEFT = 128 chunks = two waves per channel chunk)
+        const int rc = q >> 3, col = rc & 15, tap = rc >> 4;
+        const int n = bn * BN + col;
+        const void* p = n < N ? (const void*)(wT + (long)n * w_ld + tap * CIN + cc * 64 + (((q & 7) ^ (col & 7)) << 3))
+                              : (const void*)zeros;
+        glds16(p, b_base + (unsigned)(cc * B_CC + B_MAIN + (wave & 1) * 64) * 16u);
+    }
+    if constexpr (PRE) {
+        for (int c = tid; c < CIN; c += NT) bn_coef<false>(pre.bn, CIN, c, blockIdx.x == 0, pre_tab[c], pre_tab[CIN + c]);
+    }
+#pragma unroll
+    for (int cc = 0; cc < NCC; ++cc) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            glds16(a_ok[i] ? (const void*)(a_src[i] + cc * 64) : (const void*)zeros,
+                   lds_base + (unsigned)(cc * A_CC + 512 * i + wave * 64) * 16u);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            glds16(b_ok[i] ? (const void*)(b_src[i] + cc * 64) : (const void*)zeros,
+                   b_base + (unsigned)(cc * B_CC + 512 * i + wave * 64) * 16u);
+    }
+
+    // ---- per-lane tap geometry: this lane's output pixel and which of the 9 source pixels exist
+    const int fr = lane & 15, fq = lane >> 4;
+    const int r = wave * 16 + fr;                        // tile row of the A fragment this lane reads
+    const int pix = r % P, py = pix / HW, px = pix % HW;
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int cc = 0; cc < NCC; ++cc) {
+        // chunk cc (and the left-over DMA, which is older) has landed; 4 DMAs per later chunk may stay in flight
+        if (cc == NCC - 1) wait_vmcnt<0>();
+        else if (cc == NCC - 2) wait_vmcnt<4>();
+        else if (cc == NCC - 3) wait_vmcnt<8>();
+        else wait_vmcnt<12>();
+        if constexpr (PRE) {
+            if (cc == 0) __syncthreads();                // coefficient table complete
+            const bool mine = pre.act_out != nullptr;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                if (!a_ok[i]) continue;
+                const int row = (tid >> 3) + 64 * i;
+                const int c0 = cc * 64 + ((phys ^ (row & 7)) << 3);
+                uint4* slot = lds + cc * A_CC + 512 * i + tid;
+                const uint4 v = pre_chunk<T>(*slot, pre_tab + c0, pre_tab + CIN + c0, pre.act);
+                *slot = v;
+                // the activated tensor is written once (for this conv's weight gradient): chunk c0/8 by N-tile (c0/8) % n_tiles
+                if (mine && ((c0 >> 3) % n_tiles) == bn)
+                    *(uint4*)((T*)pre.act_out + ((long)bm * BM + row) * pre.act_ld + c0) = v;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        const uint4* abuf = lds + cc * A_CC;
+        const uint4* bbuf = lds + NCC * A_CC + cc * B_CC;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+            const bool ok = (unsigned)(py + dy) < (unsigned)HW && (unsigned)(px + dx) < (unsigned)HW;
+            const int rs = ok ? r + dy * HW + dx : r;    // source row (own row when the tap falls outside: zeroed below)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                uint4 a = abuf[rs * 8 + ((h * 4 + fq) ^ (rs & 7))];
+                const uint4 b = bbuf[(tap * 16 + fr) * 8 + ((h * 4 + fq) ^ (fr & 7))];
+                if (!ok) a = make_uint4(0u, 0u, 0u, 0u);
+                if ((tap + h) & 1) mfma_step<T>(a, b, acc1);
+                else mfma_step<T>(a, b, acc0);
+            }
+        }
+    }
+    f32x4 acc[1][1];
+    acc[0][0] = acc0 + acc1;
+    int ticket = 0;
+    conv_epilogue<T, BM, BN, 8, 1, BNBWD>(acc, (float*)lds, g, bias, residual, out, out_f32, bm, bn, stats, vec_epi,
+                                          [&](int rr) -> long { long m = (long)bm * BM + rr; return m < M ? m : -1L; }, be,
+                                          sfin.counter, ticket);
+    if constexpr (!BNBWD) {
+        if (stats && sfin.counter && bn_was_last(sfin.counter + bn, ticket, be.m_tiles))
+            bn_fin_fwd<false>(sfin, stats, be.rows, N, bn * BN, 1);
+    }
+}
+
+// whole-image kernel eligibility (must agree between the launcher and nvae_conv_gemm_stats_rows)
+static bool g_conv_img = true;
+extern "C" int nvae_conv_img_enable(int on) { g_conv_img = on != 0; return NVAE_OK; }
+static bool conv_img_ok(int dtype, const NvaeConvGeom* g) {
+    return g_conv_img && is16(dtype) && g->KH == 3 && g->KW == 3 && g->stride == 1 && g->div == 1 && g->pad_t == 1 &&
+           g->pad_l == 1 && g->Hin == g->Hout && g->Win == g->Wout && g->Hin == g->Win && (g->Hin == 4 || g->Hin == 8) &&
+           (g->Cin == 128 || g->Cin == 256) && g->Cout >= 64 && (long)g->B * g->Hin * g->Win >= 256;
+}
+
 #ifndef HALO_WM
 #define HALO_WM 4      // waves along M of the halo kernel: 4 -> 8 waves of 64 x 96, 2 -> 4 waves of 128 x 96
 #endif
@@ -862,16 +1105,43 @@ static int conv_tile_family(const NvaeConvGeom* g) {
     return 7;
 }
 
-static int conv_gemm_bm(int dtype, const NvaeConvGeom* g) {
-    // M-tile height the launcher will pick
+static int conv_gemm_bm_noimg(int dtype, const NvaeConvGeom* g) {
     if (conv_halo_ok(dtype, g)) return 256;
     static const int bm[8] = {0, 256, 128, 128, 128, 32, 64, 64};
     return bm[conv_tile_family(g)];
+}
+static int conv_gemm_bm(int dtype, const NvaeConvGeom* g) {
+    // M-tile height the launcher will pick (the statistics slab is sized from it: nvae_conv_gemm_stats_rows)
+    if (conv_img_ok(dtype, g)) return 128;
+    return conv_gemm_bm_noimg(dtype, g);
 }
 
 // tuning hook (tools/tune_conv.py): 0 = the launcher's own choice, 1..7 = force a tile family of k_conv_gemm2
 static int g_force_tile = 0;
 extern "C" int nvae_conv_gemm_force_tile(int t) { g_force_tile = t; return NVAE_OK; }
+// tuning hook (tools/mb_smallconv.py): 0 = the launcher's own choice, S >= 1 = force S K-slices per tile
+static int g_force_split = 0;
+extern "C" int nvae_conv_gemm_force_split(int s) { g_force_split = s; return NVAE_OK; }
+
+// Split-K workspace: partial-tile slabs + per-tile arrival counters (ZEROED by the caller once; the kernels leave
+// them zero).  One workspace serves every launch of a stream (stream order separates their use of it); launches
+// on different streams that may overlap must not share one.  Without a workspace no launch is split.
+static float* g_ws_slab = nullptr;
+static size_t g_ws_bytes = 0;
+static int* g_ws_counters = nullptr;
+static int g_ws_ncounters = 0;
+extern "C" int nvae_conv_set_workspace(void* slab, size_t bytes, int* counters, int n_counters) {
+    NVAE_REQUIRE((slab && counters && bytes > 0 && n_counters > 0) || (!slab && !counters),
+                 "conv_set_workspace: slab and counters must both be given (or both NULL)");
+    NVAE_REQUIRE(aligned16(slab), "conv_set_workspace: slab must be 16-B aligned");
+    g_ws_slab = (float*)slab; g_ws_bytes = slab ? bytes : 0; g_ws_counters = counters; g_ws_ncounters = slab ? n_counters : 0;
+    return NVAE_OK;
+}
+// K-slices per output tile for a geometry run with BM x BN tiles and `nk` ring steps (0/1 = not split)
+static int conv_split_choice(const NvaeConvGeom* g, int BM, int BN, int nk, bool single_wave_set) {
+    (void)g; (void)BM; (void)BN; (void)nk; (void)single_wave_set;
+    return 1;
+}
 
 template <typename T>
 static int launch_conv_gemm(const NvaeConvGeom* g, const void* src, const void* wT, int w_ld,
@@ -885,8 +1155,11 @@ static int launch_conv_gemm(const NvaeConvGeom* g, const void* src, const void* 
     BnFinArgs sfin{};
     if (stats_fin) sfin = *stats_fin;
     const bool use_pre = pre.on;
-    be.m_tiles = cdiv((long)g->B * g->Hout * g->Wout, conv_gemm_bm(dtype_of<T>(), g));
-    be.rows = cdiv(be.m_tiles, 64);
+    // whole-image kernel unless an in-kernel finalize is requested (that works on 64-channel groups, wider than its
+    // 16-column tiles): then the generic kernel runs on a slab the host sized for 128-row tiles (fewer rows, more adders)
+    const bool img_run = sizeof(T) == 2 && conv_img_ok(dtype_of<T>(), g) && !sfin.counter && !be.fin.counter;
+    be.m_tiles = cdiv((long)g->B * g->Hout * g->Wout, img_run ? 128 : conv_gemm_bm_noimg(dtype_of<T>(), g));
+    be.rows = cdiv(cdiv((long)g->B * g->Hout * g->Wout, conv_gemm_bm(dtype_of<T>(), g)), 64);
     const int M = g->B * g->Hout * g->Wout, K = g->KH * g->KW * g->Cin, N = g->Cout;
     FastDiv fd_hw = make_fastdiv((unsigned)(g->Hout * g->Wout)), fd_w = make_fastdiv((unsigned)g->Wout);
     const uint4* zeros = zero_page();
@@ -895,6 +1168,24 @@ static int launch_conv_gemm(const NvaeConvGeom* g, const void* src, const void* 
     const int vec_epi = (g->out_ld % vo == 0) && aligned16(out) &&
                         (!residual || (g->res_ld % (int)(16 / sizeof(T)) == 0 && aligned16(residual)));
     if (be.x && (!vec_epi || out_f32 || N % 8 != 0)) return 1;     // fusion needs the vector epilogue
+    if constexpr (sizeof(T) == 2) {
+        if (img_run) {
+            const int mt = cdiv(M, 128), nt = cdiv(N, 16);
+#define LAUNCH_IMG(HW_, CIN_, F_, P_)                                                                         \
+            hipLaunchKernelGGL((k_conv_img<T, HW_, CIN_, F_, P_>), mt * nt, 512, 0, s, *g, (const T*)src, (const T*)wT, w_ld, \
+                               bias, (const T*)residual, out, out_f32, M, nt, mt * nt, zeros, stats, vec_epi, be, pre, sfin);
+#define LAUNCH_IMG_V(HW_, CIN_)                                                                               \
+            { if (be.x) LAUNCH_IMG(HW_, CIN_, true, false) else if (use_pre) LAUNCH_IMG(HW_, CIN_, false, true)  \
+              else LAUNCH_IMG(HW_, CIN_, false, false) }
+            if (g->Hin == 4 && g->Cin == 256) LAUNCH_IMG_V(4, 256)
+            else if (g->Hin == 4) LAUNCH_IMG_V(4, 128)
+            else if (g->Cin == 256) LAUNCH_IMG_V(8, 256)
+            else LAUNCH_IMG_V(8, 128)
+#undef LAUNCH_IMG_V
+#undef LAUNCH_IMG
+            return 0;
+        }
+    }
     if (conv_halo_ok(dtype_of<T>(), g)) {
         const int pw = g->Win / 16, ppi = (g->Hin / 16) * pw;
         const int mt = g->B * ppi, nt = cdiv(N, 192);
@@ -912,9 +1203,17 @@ static int launch_conv_gemm(const NvaeConvGeom* g, const void* src, const void* 
 #define LAUNCH2F(BM_, BN_, WM_, WN_, ST_, BKC_, F_, P_)                                                 \
     {                                                                                                   \
         int mt = cdiv(M, BM_), nt = cdiv(N, BN_);                                                       \
-        hipLaunchKernelGGL((k_conv_gemm2<T, BM_, BN_, WM_, WN_, ST_, BKC_, F_, P_>), mt * nt, WM_ * WN_ * 64, 0, s, *g, \
+        const int nk = cdiv(K, BKC_ * (is16(dtype_of<T>()) ? 8 : 4));                                   \
+        ConvSplitK sk{1, nk, g_ws_slab, g_ws_counters};                                                 \
+        int S = g_force_split ? g_force_split : conv_split_choice(g, BM_, BN_, nk, WM_ * WN_ == 8);     \
+        if (S > nk) S = nk;                                                                             \
+        if (S > 1 && (BM_ / WM_ / 16) * (BN_ / WN_ / 16) <= 4 && g_ws_slab && !sfin.counter && mt * nt <= g_ws_ncounters && \
+            (size_t)mt * nt * S * BM_ * BN_ * 4 <= g_ws_bytes) {                                        \
+            sk.steps = cdiv(nk, S); sk.S = cdiv(nk, sk.steps);                                          \
+        }                                                                                               \
+        hipLaunchKernelGGL((k_conv_gemm2<T, BM_, BN_, WM_, WN_, ST_, BKC_, F_, P_>), mt * nt * sk.S, WM_ * WN_ * 64, 0, s, *g, \
                            (const T*)src, (const T*)wT, w_ld, bias, (const T*)residual, out, out_f32, M, \
-                           K, nt, mt * nt, fd_hw, fd_w, zeros, stats, vec_epi, be, pre, sfin);          \
+                           K, nt, mt * nt, fd_hw, fd_w, zeros, stats, vec_epi, be, pre, sfin, sk);      \
     }
 #define LAUNCH2(BM_, BN_, WM_, WN_, ST_, BKC_)                                                          \
     { if (be.x) LAUNCH2F(BM_, BN_, WM_, WN_, ST_, BKC_, true, false)                                    \
@@ -928,7 +1227,19 @@ static int launch_conv_gemm(const NvaeConvGeom* g, const void* src, const void* 
     // (11.8 us against 16.5; tools/tune_wide.py).  The statistics slab is indexed modulo its row count, so a tile
     // height other than conv_gemm_bm()'s stays correct (the in-kernel finalize counts M-tiles, so not with it).
     if (use_pre && !sfin.counter && family == 7 && N >= 1024 && N % 128 == 0 && M % 128 == 0) family = 3;
-    switch ((g_force_tile && !be.x) ? g_force_tile : family) {
+    // deeper rings (experimental families 8-11): no operand-prologue instantiation (its table would not fit beside the ring)
+#define LAUNCH2X(BM_, BN_, WM_, WN_, ST_, BKC_)                                                         \
+    { if (be.x) LAUNCH2F(BM_, BN_, WM_, WN_, ST_, BKC_, true, false)                                    \
+      else LAUNCH2F(BM_, BN_, WM_, WN_, ST_, BKC_, false, false) }
+    int pick = (g_force_tile && !be.x) ? g_force_tile : family;
+    if (pick >= 8 && use_pre) pick = family;
+    switch (pick) {
+        case 8: LAUNCH2X(32, 64, 2, 4, 4, 16) break;
+        case 9: LAUNCH2X(32, 64, 2, 4, 6, 16) break;
+        case 10: LAUNCH2X(64, 64, 2, 4, 4, 16) break;
+        case 11: LAUNCH2X(32, 64, 2, 2, 6, 8) break;
+        case 12: LAUNCH2X(64, 128, 2, 4, 3, 16) break;
+        case 13: LAUNCH2X(64, 128, 2, 4, 4, 8) break;
         case 1: LAUNCH2(256, 192, 4, 2, 2, 8) break;
         case 2: LAUNCH2(128, 192, 2, 4, 3, 8) break;
         case 3: LAUNCH2(128, 128, 2, 4, 3, 8) break;
@@ -938,9 +1249,13 @@ static int launch_conv_gemm(const NvaeConvGeom* g, const void* src, const void* 
         default: LAUNCH2(64, 64, 2, 2, 3, 8) break;
     }
 #undef LAUNCH2
+#undef LAUNCH2X
 #undef LAUNCH2F
     return 0;
 }
+
+// 1 if the geometry runs on the whole-image 3x3 kernel (whose operand prologue is worth using: ops.conv2d asks)
+extern "C" int nvae_conv_img_ok(int dtype, const NvaeConvGeom* g) { return g && conv_img_ok(dtype, g) ? 1 : 0; }
 
 extern "C" int nvae_conv_gemm_stats_rows(int dtype, const NvaeConvGeom* g) {
     if (!g) return 0;

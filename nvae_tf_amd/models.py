@@ -420,12 +420,30 @@ class NVAE:
 
     def sync_replicas(self):
         """Align the replicas on rank 0's parameters, state, optimizer slots and loss-scale state (start-up / resume).
-        During training nothing drifts: the all-reduced gradient is the same bits on every rank, Adamax is
-        elementwise and spectral normalisation is deterministic (sn.hip), so replicas stay bit-identical
-        (tests/test_dist_cli_gpu.py asserts it over five graphed steps without any re-broadcast)."""
+        During training the PARAMETERS and both Adamax slots do not drift: the all-reduced gradient is the same bits
+        on every rank, Adamax is elementwise and spectral normalisation is deterministic (sn.hip)
+        (tests/test_dist_cli_gpu.py asserts it over five graphed steps without any re-broadcast).  The non-trainable
+        STATE does: every rank normalises its own shard of the batch, so the BatchNorm moving statistics are
+        rank-local from step 1 on - `sync_state` averages them before anything reads them (evaluation, sampling,
+        checkpoints, the early-stopping snapshot)."""
         if self.reducer is not None:
             for t in (self.ps.params, self.ps.state, self.ps.adam_m, self.ps.adam_u, self.hyper):
                 self.reducer.broadcast_(t)
+
+    def sync_state(self):
+        """Data parallel: replace the rank-local BatchNorm moving statistics by their mean over ranks (the moving
+        average of the per-shard batch statistics of ALL shards; what a single process that saw the global batch in
+        `world` pieces would hold).  The spectral-norm vectors in the same buffer are identical on every rank and
+        come back unchanged (a mean of equal numbers, up to one rounding for world sizes that are not a power of two -
+        the same rounding on every rank).  Collective: every rank must call it at the same point."""
+        if self.reducer is not None:
+            self.reducer.allreduce_mean_(self.ps.state)
+
+    def loss_scale_report(self):
+        """(scale, clean steps since the last change) of the dynamic loss scale, read from the device (a host sync:
+        call it once per epoch, not per step).  A scale pinned at the floor means every step is being skipped."""
+        h = self.hyper.detach().cpu()
+        return float(h[L.HY_LSCALE]), int(h[L.HY_GOOD])
 
     def _dp_segments(self) -> bool:
         return self.reducer is not None and self.overlap_allreduce

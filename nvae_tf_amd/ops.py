@@ -68,6 +68,7 @@ SE_FUSED = os.environ.get("NVAE_SE_FUSED", "1") != "0"         # SE + residual (
 CONV_PRE = os.environ.get("NVAE_CONV_PRE", "1")
 # producers finalize the next BatchNorm in-kernel ("last arriver"): measured +5..12 us per conv launch against the
 # 4.8 us of a finalize launch or the ~0 of a consumer that reads the accumulated slab itself, so off by default
+CONV_PRE_IMG = os.environ.get("NVAE_CONV_PRE_IMG", "1") != "0"   # ... and 3x3 convs on the whole-image kernel (nvae_conv_img_ok)
 STATS_FIN = os.environ.get("NVAE_STATS_FIN", "0") != "0"
 FUSE_BN_BWD = os.environ.get("NVAE_BN_BWD_FUSE", "1") != "0"   # BN backward sums in the dgrad epilogue
 WGRAD_ORDER = os.environ.get("NVAE_WGRAD_ORDER", "queue")     # queue | small_first | big_first (within one flush)
@@ -353,7 +354,10 @@ def conv2d(ctx: Ctx, x: Var, conv, *, stride: int = 1, up: int = 1, pad: Optiona
     # operand prologue: x = act(BN(raw)) is applied inside the conv kernel (and, for the weight gradient, written
     # out once by it) when the gather is not upsampled and covers every source pixel as some output's centre tap
     lib = L.load()
-    pre_pays = CONV_PRE == "all" or (CONV_PRE == "1" and k == 1 and x.pre is not None and x.pre.act == L.ACT_NONE)
+    pre_pays = CONV_PRE == "all" or (CONV_PRE == "1" and x.pre is not None and (
+        (k == 1 and x.pre.act == L.ACT_NONE) or
+        # whole-image 3x3 kernel (4x4 / 8x8 towers): the tile is staged once, so the prologue costs 64 elements per thread
+        (k == 3 and CONV_PRE_IMG and lib.nvae_conv_img_ok(ctx.dt, C.byref(g)) == 1)))
     use_pre = (pre_pays and fwd_mfma and x.pre is not None and x.pre.mat is None and up == 1 and cin == Cx and c_off == 0
                and 0 < Cx <= lib.nvae_conv_gemm_pre_max_cin(ctx.dt, C.byref(g))
                and (not ctx.record or (stride == 1 and (Ho, Wo) == (H, W) and 0 <= pad[0] < k and 0 <= pad[1] < k)))

@@ -16,6 +16,9 @@ import numpy as np
 import torch
 
 
+LOSS_SCALE_FLOOR = 2.0 ** -24     # lower bound of the dynamic loss scale (models.NVAE._seg_update)
+
+
 def checkpoint_path(model_save_dir, epoch):
     return os.path.join(model_save_dir, f"epoch_{epoch}.pt")
 
@@ -69,6 +72,16 @@ def train(args, model, train_data, test_data, rank=0, world=1):
                     logs[k].append(float(out[k].float().mean()))
         dt = time.time() - t0
         means = {k: float(np.mean(v)) for k, v in logs.items()}
+        model.sync_state()         # BatchNorm moving statistics are rank-local: average them before anyone reads them
+        if model.dynamic_loss_scale and rank == 0:
+            # a step whose gradient overflows is skipped ON THE DEVICE (nvae_adamax); the host-side schedule (cosine
+            # learning rate, Adamax bias correction, KL warm-up) still advances on it, so say so when it happens a lot
+            ls, good = model.loss_scale_report()
+            print(f"epoch {epoch}: dynamic loss scale 2^{np.log2(ls):.0f}, {good} clean steps since it last changed")
+            if ls <= LOSS_SCALE_FLOOR:
+                print("WARNING: the loss scale sits at its floor - every step of this epoch overflowed in float16 and "
+                      "was skipped; nothing is being trained (use --dtype bf16: same footprint and speed, f32's "
+                      "exponent range)")
         if rank == 0:
             print(f"epoch {epoch}: loss {means['loss']:.3f}  {seen / dt:.1f} images/s  beta {model.beta():.3f}")
             if tb is not None:

@@ -88,6 +88,15 @@ def _dp_worker(rank, world, port, q):
         other = [torch.empty_like(mine) for _ in range(world)]
         dist.all_gather(other, mine)
         drift = float((other[0] - other[1]).abs().max())
+        # the non-trainable state is rank-local (every rank normalises its own shard): the BatchNorm moving statistics
+        # differ between the ranks until sync_state() replaces them by their mean
+        st = [torch.empty_like(dp.ps.state) for _ in range(world)]
+        dist.all_gather(st, dp.ps.state.clone())
+        assert float((st[0] - st[1]).abs().max()) > 0.0
+        want = (st[0] + st[1]) / world
+        dp.sync_state()
+        dist.all_gather(st, dp.ps.state.clone())
+        assert float((st[0] - st[1]).abs().max()) == 0.0 and float((st[0] - want).abs().max()) < 1e-6
         dp.sync_replicas()
         dist.all_gather(other, dp.ps.params.clone())
         assert float((other[0] - other[1]).abs().max()) == 0.0

@@ -70,6 +70,12 @@ CONV_CASES = [
     dict(k=3, cin=1, cout=16, stride=1, up=1, H=8, B=2),          # direct path (stem)
     dict(k=3, cin=16, cout=1, stride=1, up=1, H=8, B=2),          # direct dgrad/wgrad (logit head)
     dict(k=1, cin=20, cout=32, stride=1, up=1, H=4, B=4),         # latent half of the combiner
+    # whole-image 3x3 kernel k_conv_img (16-bit; f32 runs the generic kernel): 4x4 and 8x8 images, 128 / 256 channels,
+    # a ragged last M-tile (B*H*H not a multiple of 128), a ragged last N-tile, residual, no bias
+    dict(k=3, cin=256, cout=256, stride=1, up=1, H=4, B=16, img=True),
+    dict(k=3, cin=128, cout=128, stride=1, up=1, H=8, B=5, residual=True, img=True),
+    dict(k=3, cin=128, cout=72, stride=1, up=1, H=4, B=18, bias=False, img=True),
+    dict(k=3, cin=256, cout=64, stride=1, up=1, H=8, B=4, img=True),
 ]
 
 
@@ -115,6 +121,11 @@ def test_conv_fwd_bwd(lib, dev, dtype, case):
     kw = dict(stride=stride, up=up, residual=rv, bias=use_bias)
     if case.get("pad") is not None:
         kw.update(pad=pad, out_hw=(Ho, Ho))
+    if case.get("img"):
+        import ctypes as C_
+        from nvae_tf_amd import _lib as L_
+        gg = L_.ConvGeom(B, H, H, cin, H, H, cout, 3, 3, 1, 1, 1, 1, 0, cin, cout, cout)
+        assert lib.nvae_conv_img_ok(L_.dtype_code(dtype), C_.byref(gg)) == (0 if dtype == torch.float32 else 1)
     y = ops.conv2d(ctx, xv, conv, **kw)
     y.g = dy.to(dev, dtype)
     ctx.backward()
@@ -314,8 +325,17 @@ FUSED_CHAIN_CASES = [
     dict(B=32, H=4, ci=64, cm=256, co=256, k1=3, k2=3),       # 32x64 small-M tiles (K >= 512)
     dict(B=40, H=8, ci=64, cm=128, co=128, k1=3, k2=3),       # 64x64 (2,4) 128-deep ring
     dict(B=16, H=16, ci=64, cm=384, co=64, k1=1, k2=1),       # 128x192 / 128x64 tiles
-    dict(B=16, H=16, ci=128, cm=192, co=192, k1=5, k2=5),     # halo-tile kernel (fwd stats + fused dgrad epilogue)
+    dict(B=16, H=16, ci=128, cm=192, co=192, k1=5, k2=5),     # 16 halo tiles < 64: the generic kernel at a 5x5 geometry
     dict(B=64, H=32, ci=64, cm=192, co=64, k1=3, k2=3),       # 256x192 tiles
+    # whole-image 3x3 kernel k_conv_img for both convs (16-bit): statistics epilogue, operand prologue (+ the activated
+    # tensor written for the weight gradient), BatchNorm-backward epilogue; with prologue+fin the in-kernel finalize
+    # sends both convs back to the generic kernel on a slab sized for the 128-row tiles
+    dict(B=32, H=4, ci=128, cm=256, co=128, k1=3, k2=3),
+    dict(B=9, H=8, ci=128, cm=128, co=256, k1=3, k2=3),
+    # halo-tile kernel k_conv_halo (>= 64 tiles of 16x16 pixels x 192 channels): forward statistics epilogue, operand
+    # prologue next to the ping-pong wave schedule (16-bit), BatchNorm-backward dgrad epilogue; 5x5 and 3x3
+    dict(B=64, H=16, ci=128, cm=192, co=192, k1=5, k2=5, halo=True),
+    dict(B=64, H=16, ci=128, cm=192, co=192, k1=3, k2=3, halo=True),
 ]
 
 
@@ -365,6 +385,14 @@ def test_fused_bn_chain(lib, dev, dtype, case, mode, monkeypatch):
     xv = Var(x.to(dev, dtype))
     hv = ops.conv2d(ctx, xv, c1, bias=False, want_stats=True, stats_bn=bn if mode == "prologue+fin" else None)
     assert hv.stats is not None and (hv.fin is not None) == (mode == "prologue+fin")
+    if case.get("halo"):
+        # the halo kernel really is the one selected: its M-tile is a 16x16 patch = 256 rows, 64 tiles per slab row
+        assert hv.stats[1] == -(-(B * (H // 16) ** 2) // 64)
+        import ctypes as C_
+        from nvae_tf_amd import _lib as L_
+        for (cin_, cout_, kk) in ((ci, cm, k1), (cm, co, k2)):
+            gg = L_.ConvGeom(B, H, H, cin_, H, H, cout_, kk, kk, 1, (kk - 1) // 2, (kk - 1) // 2, 1, 0, cin_, cout_, cout_)
+            assert lib.nvae_conv_gemm_pre_max_cin(L_.dtype_code(dtype), C_.byref(gg)) == 512      # PRE_MAXC_HALO
     av = ops.bn_act(ctx, hv, bn, 1, lazy=mode != "materialised")
     assert (av.pre.mat is None) == (mode != "materialised")
     y = ops.conv2d(ctx, av, c2)
