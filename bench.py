@@ -162,7 +162,7 @@ def time_hbm_kernels(model, batch, iters=30):
         w2, b2 = torch.randn(hd, ch, device=dev) * 0.1, torch.zeros(ch, device=dev)
         pooled, gate = torch.empty(batch, ch, device=dev), torch.empty(batch, ch, device=dev)
         hidden = torch.empty(batch, hd, device=dev)
-        se_rows = lib.nvae_se_fused_rows(batch)
+        se_rows = lib.nvae_se_fused_rows(batch, hw * hw, ch)
         st, part = torch.zeros(se_rows, 2, ch, device=dev), torch.zeros(se_rows, 2, ch, device=dev)
         scratch = torch.empty(batch, ch + hd, device=dev)
         if ch & (ch - 1) == 0:
@@ -334,7 +334,9 @@ def time_dp_configured(args, device, dtype, x, plain_ms):
     if own_group:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", str(29500 + os.getpid() % 400))
-        dist.init_process_group("nccl", rank=0, world_size=1, device_id=device)
+        with parallel.stdout_to_stderr():
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=device)
+            dist.all_reduce(torch.zeros(1, device=device)); torch.cuda.synchronize()
     try:
         m = make_model(device, dtype, args.batch)
         m.reducer = parallel.GradReducer(force=True)

@@ -341,9 +341,17 @@ int nvae_se_bwd_apply(int dtype, const void* dy, const float* gate, const float*
  * bn (may be NULL: no BatchNorm): see NvaeBnIn - the BatchNorm's output is never materialised.
  * C: a power of two in [8, 2048].  pooled_sum [B,C] (sum over HW of xs), gate [B,C], hidden [B,Hd] are
  * outputs (the backward pass and nvae_se_wgrad_batched read them).
- * stats (may be NULL; ZEROED): [nvae_se_fused_rows(B)][2][C] statistics slab of y for the BatchNorm that
+ * stats (may be NULL; ZEROED): [nvae_se_fused_rows(B, HW, C)][2][C] statistics slab of y for the BatchNorm that
  * follows (accumulated with atomics, <= 64 adders per address).                                        */
-int nvae_se_fused_rows(int B);
+int nvae_se_fused_rows(int B, int HW, int C);
+/* Workspace of the image-split form of the two kernels below: with <= 64 images per launch (BASELINE.json configs[3],
+ * [4]) and images of >= 32 K elements, S workgroups share an image (S * B <= 256) and hand the pooled vector / the gate
+ * (backward: r / dpool) to each other through `buf` (>= (B*S*C + B*C) * 4 bytes) and per-image arrival counters
+ * (n_counters >= B ints, ZEROED once by the caller; the kernels leave them zero).  Results are independent of the
+ * arrival order (slice-ordered sums).  Launches sharing a workspace must be stream-ordered.  NULL / NULL: never split. */
+int nvae_se_set_workspace(void* buf, size_t bytes, int* counters, int n_counters);
+/* Tuning / test hook: -1 = the launcher's choice (default), 1 = never split, S >= 2 = S slices per image where legal. */
+int nvae_se_force_split(int S);
 int nvae_se_fused_fwd(int dtype, const void* x, const NvaeBnIn* bn, const void* skip, void* y, int B, int HW,
                       int C, int Hd, const float* w1, const float* b1, const float* w2, const float* b2,
                       float skip_scale, float branch_scale, float* pooled_sum, float* gate, float* hidden,
@@ -351,7 +359,7 @@ int nvae_se_fused_fwd(int dtype, const void* x, const NvaeBnIn* bn, const void* 
 /* Backward of the same block: dx (+)= d/dxs, dskip (+)= skip_scale*dy (dskip may be NULL), FC gradient
  * scratch [B*(C+Hd)] for nvae_se_wgrad_batched.  act: activation of the folded BatchNorm (none / swish).
  * partials (may be NULL; needs bn_scale and acc_dx == 0; ZEROED): dxs is final, so the BatchNorm-backward
- * sums of the folded layer are accumulated in the same pass: partials[nvae_se_fused_rows(B)][2][C] for
+ * sums of the folded layer are accumulated in the same pass: partials[nvae_se_fused_rows(B, HW, C)][2][C] for
  * nvae_bn_bwd_apply_fin / nvae_bn_bwd_finalize_s.                                                    */
 int nvae_se_fused_bwd(int dtype, const void* x, const float* bn_scale, const float* bn_shift, int act,
                       const void* dy, const float* gate, const float* hidden, void* dx, void* dskip, int B,

@@ -112,6 +112,8 @@ _SIGS = {
     "nvae_se_bwd_apply": [_i, _p, _p, _p, _p, _p, _i, _i, _i, _f, _f, _i, _i],
     "nvae_se_bwd_apply_bn": [_i, _p, _p, _p, _p, _p, _i, _i, _i, _f, _f, _i, _p, _p, _p, _i, _p],
     "nvae_se_fused_rows": None,
+    "nvae_se_set_workspace": None,
+    "nvae_se_force_split": None,
     "nvae_se_fused_fwd": [_i, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _f, _f, _p, _p, _p, _p],
     "nvae_se_fused_bwd": [_i, _p, _p, _p, _i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _f, _f, _i, _i, _p, _p],
     "nvae_unary_fwd": [_i, _i, _p, _p, _l, _f, _f],
@@ -164,7 +166,11 @@ def load():
     lib.nvae_reduce_splits.restype = C.c_int
     lib.nvae_reduce_splits.argtypes = [_l, _i]
     lib.nvae_se_fused_rows.restype = C.c_int
-    lib.nvae_se_fused_rows.argtypes = [_i]
+    lib.nvae_se_fused_rows.argtypes = [_i, _i, _i]
+    lib.nvae_se_set_workspace.restype = C.c_int
+    lib.nvae_se_set_workspace.argtypes = [_p, C.c_size_t, _p, _i]
+    lib.nvae_se_force_split.restype = C.c_int
+    lib.nvae_se_force_split.argtypes = [_i]
     lib.nvae_dwconv5_stats_rows.restype = C.c_int
     lib.nvae_dwconv5_stats_rows.argtypes = [_i, _i, _i, _i, _i]
     lib.nvae_conv_gemm_stats_rows.restype = C.c_int
@@ -193,6 +199,30 @@ def load():
         fn.argtypes = [*sig, _p]
     _lib = lib
     return lib
+
+
+_workspace = {}
+
+
+def ensure_workspace(device) -> None:
+    """Register the split-K workspace of the implicit-GEMM kernel (include/nvae_hip.h nvae_conv_set_workspace) for
+    this process: 32 MB of partial-tile slabs + 4096 zeroed arrival counters, allocated once and never freed (the
+    library keeps the raw pointers).  One process drives one GPU and issues its convolutions on one stream."""
+    dev = torch.device(device)
+    if dev.type != "cuda" or "ws" in _workspace:
+        return
+    slab = torch.empty(32 << 20, dtype=torch.uint8, device=dev)
+    counters = torch.zeros(4096, dtype=torch.int32, device=dev)
+    rc = load().nvae_conv_set_workspace(slab.data_ptr(), slab.numel(), counters.data_ptr(), counters.numel())
+    if rc != 0:
+        raise RuntimeError(f"nvae_conv_set_workspace failed: {load().nvae_last_error().decode()}")
+    se_buf = torch.empty(8 << 20, dtype=torch.uint8, device=dev)       # SE image-split hand-off vectors
+    se_counters = torch.zeros(256, dtype=torch.int32, device=dev)
+    rc = load().nvae_se_set_workspace(se_buf.data_ptr(), se_buf.numel(), se_counters.data_ptr(), se_counters.numel())
+    if rc != 0:
+        raise RuntimeError(f"nvae_se_set_workspace failed: {load().nvae_last_error().decode()}")
+    _workspace["ws"] = (slab, counters)
+    _workspace["se"] = (se_buf, se_counters)
 
 
 def ptr(t):

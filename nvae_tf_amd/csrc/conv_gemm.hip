@@ -1063,7 +1063,7 @@ extern "C" int nvae_conv_img_enable(int on) { g_conv_img = on != 0; return NVAE_
 static bool conv_img_ok(int dtype, const NvaeConvGeom* g) {
     return g_conv_img && is16(dtype) && g->KH == 3 && g->KW == 3 && g->stride == 1 && g->div == 1 && g->pad_t == 1 &&
            g->pad_l == 1 && g->Hin == g->Hout && g->Win == g->Wout && g->Hin == g->Win && (g->Hin == 4 || g->Hin == 8) &&
-           (g->Cin == 128 || g->Cin == 256) && g->Cout >= 64 && (long)g->B * g->Hin * g->Win >= 256;
+           (g->Cin == 128 || g->Cin == 256) && g->Cout >= 32 && (long)g->B * g->Hin * g->Win >= 256;
 }
 
 #ifndef HALO_WM
@@ -1138,8 +1138,14 @@ extern "C" int nvae_conv_set_workspace(void* slab, size_t bytes, int* counters, 
     return NVAE_OK;
 }
 // K-slices per output tile for a geometry run with BM x BN tiles and `nk` ring steps (0/1 = not split)
-static int conv_split_choice(const NvaeConvGeom* g, int BM, int BN, int nk, bool single_wave_set) {
-    (void)g; (void)BM; (void)BN; (void)nk; (void)single_wave_set;
+// Measured (tools/mb_smallconv.py, profiles/r03_mb_smallconv.txt): on the tower shapes with >= 128 output channels
+// no split beats the unsplit launch by more than 0.5 us - the kernels are bound by the bytes a CU pulls through its
+// L1 and the slab hand-off costs what the shorter K loop saves - so those are not split (the 3x3 ones run
+// k_conv_img instead).  Narrow layers whose grid leaves most of the chip idle are: the 3x3 sampler convs
+// (common.py:36-47, 256 -> 40 at 4x4: 64 workgroups) run 12.2 -> 8.2 us with three K-slices.
+static int conv_split_choice(const NvaeConvGeom* g, int BM, int BN, int nk, bool eight_waves) {
+    const long tiles = (long)cdiv((long)g->B * g->Hout * g->Wout, BM) * cdiv(g->Cout, BN);
+    if (eight_waves && g->Cout <= 64 && nk >= 9 && tiles <= 96) return 3;
     return 1;
 }
 

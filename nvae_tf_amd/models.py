@@ -34,6 +34,11 @@ OVERLAP_PREP = os.environ.get("NVAE_OVERLAP_PREP", "1") != "0"      # SN + weigh
 # backward pass into segments flushes the weight-gradient queue five times, and smaller same-shape batches cost more
 # than the 0.3 ms of Adamax that gets hidden (the NVAE_WGRAD_FLUSH sweep shows the same: 32 -> 22.0, 256 -> 20.7 ms)
 OVERLAP_ADAMAX = os.environ.get("NVAE_OVERLAP_ADAMAX", "0") != "0"
+# data parallel: backward segments (each its own hipGraph, its gradient range all-reduced while the next one runs):
+# 5 = postprocess | decoder | three encoder + preprocess pieces, 4 / 3 = fewer encoder cuts, 2 = postprocess + decoder |
+# encoder + preprocess, 1 = one backward graph and one all-reduce behind it (no overlap)
+DP_SEGMENTS = int(os.environ.get("NVAE_DP_SEGMENTS", "5"))
+DP_DW_PRE = os.environ.get("NVAE_DP_DW_PRE", "0") != "0"      # keep the depthwise BN prologue when data parallel
 
 
 class NVAE:
@@ -116,7 +121,7 @@ class NVAE:
         self.reducer = None     # parallel.GradReducer when data-parallel
         # DP: backward runs in tape segments (postprocess | decoder | encoder top | encoder middle | encoder bottom +
         # preprocess); the parameters of a finished segment are all-reduced while the next one computes
-        self.overlap_allreduce = True
+        self.overlap_allreduce = DP_SEGMENTS > 1
         self._tape_marks = (0, 0)
         self._segments = []          # [(tape_lo, tape_hi, grad_lo, grad_hi)] in backward order, set by _forward
         dev = self.device
@@ -221,12 +226,15 @@ class NVAE:
         range (45 % of the parameters) is cut twice at encoder group boundaries, so that the all-reduce left
         exposed after the last kernel covers about a quarter of it (24 MB at C2) instead of 108 MB."""
         m = self.param_marks
+        nseg = DP_SEGMENTS
+        if nseg <= 2:      # postprocess + decoder | encoder + preprocess
+            return [(enc_mark, end, m[2], m[4]), (0, enc_mark, m[0], m[2])]
         segs = [(dec_mark, end, m[3], m[4]), (enc_mark, dec_mark, m[2], m[3])]
         enc = self.encoder
         offs, idxs = enc.group_param_off, enc.group_tape_idx
         total = m[2] - m[0]
         cuts = []
-        for frac in (0.6, 0.25):
+        for frac in {3: (), 4: (0.45,)}.get(nseg, (0.6, 0.25)):
             cand = [i for i in range(1, len(offs)) if offs[i] - m[0] <= frac * total and idxs[i] > 0]
             if cand and (not cuts or cand[-1] < cuts[-1]):
                 cuts.append(cand[-1])
@@ -347,7 +355,7 @@ class NVAE:
         self._prepare_weights_staged(spectral_norm and not self.tf_literal)
         ctx = Ctx(ps, self.dtype, training=not self.tf_literal, record=True,
                   side_stream=self._side if self.overlap_wgrad else None)
-        ctx.dw_pre = self.reducer is None
+        ctx.dw_pre = self.reducer is None or DP_DW_PRE
         self._bn_loss = ctx.zeros_f32(1)
         nb = len(ps.bn_loss_layers)
         if nb:

@@ -704,7 +704,7 @@ def se_residual(ctx: Ctx, x: Var, se, skip: Var, skip_scale: float, branch_scale
         # pool + FC + gate + residual add (+ the BatchNorm in front, + the statistics of y) in ONE launch
         slab = None
         if ctx.training and SE_STATS:
-            S = L.load().nvae_se_fused_rows(B)
+            S = L.load().nvae_se_fused_rows(B, HW, Cc)
             slab = ctx.zero_slab(S, Cc)
             y.stats = (slab, S)
         call("nvae_se_fused_fwd", ctx.dt, ptr(xin_t), bn_in, ptr(skip.t), ptr(y.t), B, HW, Cc, Hd,
@@ -741,7 +741,7 @@ def se_residual(ctx: Ctx, x: Var, se, skip: Var, skip_scale: float, branch_scale
                 part = None
                 if fuse:
                     # x = act(BN(xb)) with this SE as its only consumer: dx is final, reduce the BN backward sums here
-                    S = L.load().nvae_se_fused_rows(B)
+                    S = L.load().nvae_se_fused_rows(B, HW, Cc)
                     src["partials"] = ctx.zero_slab(S, Cc)
                     src["k0k1"] = ctx.empty((2, Cc), torch.float32)
                     src["mtiles"] = S

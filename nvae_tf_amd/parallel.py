@@ -88,6 +88,24 @@ class GradReducer:
         return flat
 
 
+class stdout_to_stderr:
+    """RCCL prints a version banner on stdout when its first communicator comes up; programs whose stdout is a
+    protocol (bench.py: one JSON line) wrap the initialisation and the first collective in this."""
+
+    def __enter__(self):
+        import os, sys
+        sys.stdout.flush()
+        self._saved = os.dup(1)
+        os.dup2(2, 1)
+        return self
+
+    def __exit__(self, *exc):
+        import os, sys
+        sys.stdout.flush()
+        os.dup2(self._saved, 1)
+        os.close(self._saved)
+
+
 def init_from_env(device_index: Optional[int] = None):
     """Initialise torch.distributed from torchrun's environment.  Returns (rank, world, local_rank)."""
     import os
@@ -103,5 +121,9 @@ def init_from_env(device_index: Optional[int] = None):
         if torch.cuda.is_available():
             n_dev = max(torch.cuda.device_count(), 1)
             torch.cuda.set_device((local if device_index is None else device_index) % n_dev)
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        with stdout_to_stderr():
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
+            if backend == "nccl":      # bring the communicator up now (and its banner with it)
+                dist.all_reduce(torch.zeros(1, device="cuda"))
+                torch.cuda.synchronize()
     return rank, world, local

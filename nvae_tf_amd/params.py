@@ -151,6 +151,7 @@ class ParamStore:
             (host_s if state else host_p)[slot.off:slot.off + slot.numel] = init
         self._init.clear()
         self.device, self.dtype = device, dtype
+        L.ensure_workspace(device)
         self.params = host_p.to(device)
         self.state = host_s.to(device)
         self.grads = torch.zeros(P, dtype=torch.float32, device=device)

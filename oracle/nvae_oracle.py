@@ -338,8 +338,20 @@ class OracleNVAE:
                 w.div_(sigma)
                 self.s.state[name + ".u"] = un.reshape(-1)
 
+    # `act_round` (None = exact arithmetic): emulation of a 16-bit activation path for the parity tests' error model.
+    # The HIP kernels keep f32 accumulators, statistics and weights master copies but STORE activations (conv /
+    # depthwise outputs, materialised BatchNorm(+Swish) outputs, SE + residual outputs) and read weights in the 16-bit
+    # type.  With act_round set, the oracle rounds the same tensors (straight-through for the gradient), which gives
+    # the spread a correct 16-bit implementation has around the exact result, per gradient tensor
+    # (tests/test_model_gpu.py::bf16_spread).  It is not a bit model of the kernels.
+    act_round = None
+
+    def _r(self, x):
+        return x if self.act_round is None else x + (self.act_round(x.detach()) - x.detach())
+
     def conv(self, name, x, stride=1):
-        return conv2d(x, self.P(name + ".w"), self.s.params.get(name + ".b"), stride)
+        w = self.P(name + ".w")
+        return self._r(conv2d(x, w if self.act_round is None else self._r(w), self.s.params.get(name + ".b"), stride))
 
     def bn(self, name, x, training):
         """Keras BatchNormalization(momentum=.05, epsilon=1e-5) (a23)."""
@@ -354,14 +366,14 @@ class OracleNVAE:
                                               + (1 - BN_MOMENTUM) * var.detach())
         else:
             mean, var = self.s.state[name + ".rm"], self.s.state[name + ".rv"]
-        return (x - mean) * torch.rsqrt(var + BN_EPS) * g + b
+        return self._r((x - mean) * torch.rsqrt(var + BN_EPS) * g + b)
 
     def se(self, name, x):
         """SqueezeExcitation.call, common.py:127-142."""
         p = x.mean(dim=(1, 2))
         h = torch.relu(p @ self.P(name + ".w1") + self.P(name + ".b1"))
         gate = torch.sigmoid(h @ self.P(name + ".w2") + self.P(name + ".b2"))
-        return x * gate[:, None, None, :]
+        return self._r(x * gate[:, None, None, :])
 
     def rescaler(self, name, x, up: bool, training):
         """Rescaler.call, common.py:164-174."""
@@ -421,7 +433,7 @@ class OracleNVAE:
         y = self.bn(n + ".bn1", x, training)
         y = self.conv(n + ".conv1", y)
         y = swish(self.bn(n + ".bn2", y, training))
-        y = dwconv5(y, self.P(n + ".dw.w"), self.P(n + ".dw.b"))
+        y = self._r(dwconv5(y, self.P(n + ".dw.w"), self.P(n + ".dw.b")))
         y = swish(self.bn(n + ".bn3", y, training))
         y = self.conv(n + ".conv2", y)
         y = self.bn(n + ".bn4", y, training)

@@ -53,11 +53,49 @@ def rel(a, b):
     return float((a - b).abs().max() / (b.abs().max() + 1e-12))
 
 
+def oracle_16bit(orc, snap, x, eps, jitter=None, dt=torch.bfloat16):
+    """One training-mode forward + backward of the oracle with its stored activations and conv weights rounded to the
+    16-bit type `dt` (OracleNVAE.act_round), from the parameter / state snapshot `snap`.  jitter: None = round to nearest;
+    a torch.Generator = every value is first nudged by up to half an ulp (which neighbour it lands on becomes
+    arbitrary: the noise that f32 atomics / summation orders put under the kernels' rounding).  -> (loss dict, grads)."""
+    def rnd(t):
+        if jitter is not None:
+            t = t * (1.0 + (torch.rand(t.shape, generator=jitter, dtype=t.dtype) - 0.5) * 2.0 ** -8)
+        return t.to(dt).to(t.dtype)
+    orc.s.params = {k: v.clone().requires_grad_(True) for k, v in snap[0].items()}
+    orc.s.state = {k: v.clone() for k, v in snap[1].items()}
+    orc.act_round = rnd
+    try:
+        orc.spectral_norm_step()
+        out = orc.loss(x, eps, training=True)
+        names = list(orc.s.params)
+        gs = torch.autograd.grad(out["loss"], [orc.s.params[k] for k in names], allow_unused=True)
+    finally:
+        orc.act_round = None
+    return out, {k: (g if g is not None else torch.zeros_like(orc.s.params[k])) for k, g in zip(names, gs)}
+
+
+def bf16_spread(orc, snap, x, eps, exact, runs=6, dt=torch.bfloat16):
+    """How far a CORRECT bf16 implementation can sit from the fp64 result, per gradient tensor: the oracle itself with
+    16-bit storage (oracle_16bit: round-to-nearest once, then `runs - 1` jittered runs), each compared with the exact
+    gradient.  Returns {name: max relative error over the runs}.  Tensors for which this is O(1) are ill-conditioned
+    at this input (a ReLU kink of an SE hidden unit, a BatchNorm beta whose gradient nearly cancels): the test widens
+    THEIR bound, by name, instead of exempting a blanket share of all tensors."""
+    spread = {k: 0.0 for k in exact}
+    gen = torch.Generator().manual_seed(1234)
+    for r in range(runs):
+        _, gs = oracle_16bit(orc, snap, x, eps, gen if r else None, dt)
+        for k, g in gs.items():
+            spread[k] = max(spread[k], rel(g, exact[k]))
+    return spread
+
+
 @pytest.mark.parametrize("dtype,ltol,gtol", [(torch.float32, 1e-3, 5e-3), (torch.bfloat16, 3e-2, 0.2),
                                              (torch.float16, 5e-3, 0.1)], ids=["f32", "bf16", "f16"])
 def test_train_step_parity(lib, dev, dtype, ltol, gtol):
     orc, model, x, eps = build_pair(dev, dtype)
     orc.steps = model.steps = 100          # beta = 1/3 -> KL balancing active
+    snap = ({k: v.detach().clone() for k, v in orc.s.params.items()}, {k: v.clone() for k, v in orc.s.state.items()})
     out_o = orc.train_step(x, eps, decay_steps=1000)
     out = model.train_step(x.float(), [e.float() for e in eps])
     torch.cuda.synchronize()
@@ -83,12 +121,19 @@ def test_train_step_parity(lib, dev, dtype, ltol, gtol):
     if dtype != torch.bfloat16:
         assert not bad, bad[:10]
     else:
-        # bf16, measured over the 256 tensors with a real gradient (four runs): median 2.4-2.5e-2, 90th percentile
-        # 4.3-4.5e-2, 98th 6.6e-2-0.11; the worst tensor is 0.11-0.14 in three runs and 1.0 in one (post.cell0.se.b1,
-        # bn3.beta, se.w1: sums that nearly cancel, e.g. a BN beta behind the 0.1-scaled SE branch, so their bf16
-        # rounding noise is O(1) of a tiny true value; the f32 and f16 runs of the same kernels have no such tensor).
-        # Round 1 allowed 0.4 and exempted 2 %; now 0.2 with at most 2 % exempt, plus bounds on the distribution.
-        assert len(bad) <= max(2, len(valid) // 50), bad[:10]
+        # bf16.  Round 2 exempted a blanket 2 % of the tensors after one run in four showed post.cell0.se.b1 / se.w1 /
+        # bn3.beta at 0.4-1.0 of their scale.  Now every tensor has its own bound: max(gtol, 3 x the spread a correct
+        # bf16 implementation has at THIS input, measured on the oracle itself: bf16_spread above).  The tensors that get
+        # a widened bound are listed; they are the ones the emulation itself moves by more than gtol / 3 (profiles/
+        # r03_bf16_spread.txt: SE parameters of cells where a hidden unit sits at its ReLU kink, and the BatchNorm in
+        # front of that SE).  Everything else - and the distribution as a whole - keeps the tight bound.
+        orc.steps = 100
+        spread = bf16_spread(orc, snap, x, eps, out_o["grads"])
+        widened = sorted(((v, k) for k, v in spread.items() if 3 * v > gtol), reverse=True)
+        print("tensors whose own bf16 spread exceeds gtol / 3 (bound widened to 3 x spread):", widened[:12])
+        assert len(widened) <= max(4, len(valid) // 25), widened
+        over = [(e, k, spread[k]) for e, k in bad if e > max(gtol, 3 * spread[k])]
+        assert not over, over[:10]
         assert valid[len(valid) // 2] < 5e-2 and valid[len(valid) * 9 // 10] < 9e-2
     # direction of the whole gradient
     go = torch.cat([out_o["grads"][k].reshape(-1) for k in out_o["grads"]])
@@ -403,3 +448,47 @@ def test_c2_architecture_parity(lib, dev, batch):
     else:
         assert cos > 0.993                         # measured 0.9971; f32 PyTorch vs fp64 PyTorch: 0.9958 (see the docstring)
         assert med < 0.15                          # measured 6.6e-2
+
+
+def test_c2_architecture_parity_bf16(lib, dev):
+    """The benchmarked configuration in the benchmarked dtype: C2 architecture at full width and depth, batch 2, bf16 HIP
+    path vs the fp64 oracle.  What bf16 can show through 330 layers at a random initialisation is set by the
+    conditioning of the network, not by the kernels, so the yardstick is the oracle ITSELF with bf16 storage
+    (oracle_16bit): the HIP path must be as close to the exact result as that emulation is (loss, per-group KL,
+    direction of the 62 M-element gradient, per-tensor error distribution), within stated factors."""
+    cfg = dict(CFG, n_encoder_channels=32, n_decoder_channels=32, res_cells_per_group=2, n_preprocess_cells=3,
+               n_post_process_cells=3, n_groups_per_scale=[5, 10])
+    global B
+    old_b, B = B, 2
+    try:
+        orc, model, x, eps = build_pair(dev, torch.bfloat16, cfg)
+    finally:
+        B = old_b
+    assert model.n_trainable() == 62225021 and model.n_groups == 15
+    orc.steps = model.steps = 100
+    snap = ({k: v.detach().clone() for k, v in orc.s.params.items()}, {k: v.clone() for k, v in orc.s.state.items()})
+    out_o = orc.train_step(x, eps, decay_steps=1000)
+    out = model.train_step(x.float(), [e.float() for e in eps])
+    torch.cuda.synchronize()
+    orc.steps = 100
+    out_e, g_e = oracle_16bit(orc, snap, x, eps)
+    names = [k for k in out_o["grads"] if float(out_o["grads"][k].abs().max()) > 1e-6]
+    go = torch.cat([out_o["grads"][k].reshape(-1) for k in out_o["grads"]])
+
+    def stats(get):
+        gp = torch.cat([get(k).double().cpu().reshape(-1) for k in out_o["grads"]])
+        errs = sorted(rel(get(k), out_o["grads"][k]) for k in names)
+        return float((go * gp).sum() / (go.norm() * gp.norm())), errs[len(errs) // 2], errs[len(errs) * 9 // 10]
+    cos_h, med_h, p90_h = stats(lambda k: model.ps.get_grad(k))
+    cos_e, med_e, p90_e = stats(lambda k: g_e[k])
+    lo = float(out_o["loss"])
+    dl_h, dl_e = abs(float(out["loss"]) - lo) / abs(lo), abs(float(out_e["loss"]) - lo) / abs(lo)
+    kl_h = max(rel(out["kl_per_group"][gi], out_o["kl_per_group"][gi]) for gi in range(15))
+    kl_e = max(rel(out_e["kl_per_group"][gi], out_o["kl_per_group"][gi]) for gi in range(15))
+    print(f"C2 bf16 batch 2 vs fp64: HIP loss {dl_h:.2e} worst KL group {kl_h:.2e} cosine {cos_h:.5f} per-tensor median "
+          f"{med_h:.2e} p90 {p90_h:.2e} | oracle with bf16 storage: loss {dl_e:.2e} KL {kl_e:.2e} cosine {cos_e:.5f} "
+          f"median {med_e:.2e} p90 {p90_e:.2e}")
+    assert dl_h < max(3e-2, 3 * dl_e)                     # the shrunken model's bound, or 3 x the emulation's own distance
+    assert kl_h < max(6e-2, 3 * kl_e)
+    assert 1 - cos_h < max(2e-2, 3 * (1 - cos_e))
+    assert med_h < max(8e-2, 2 * med_e) and p90_h < max(0.2, 2 * p90_e)

@@ -141,6 +141,52 @@ def test_conv_fwd_bwd(lib, dev, dtype, case):
 
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16", "f16"])
+@pytest.mark.parametrize("shape", [(32, 4, 256, 40, 3), (16, 8, 128, 128, 3), (24, 4, 1536, 256, 1), (3, 8, 768, 72, 1)],
+                         ids=lambda s: "B{}_H{}_{}-{}_k{}".format(*s))
+def test_conv_split_k(lib, dev, dtype, shape):
+    """Split-K of the generic implicit GEMM (nvae_conv_set_workspace): S = 2, 3, 5 K-slices per tile against the unsplit
+    launch and an fp64 reference; the slice-ordered sum makes the result independent of the arrival order (bit-equal
+    over repeated launches) and the arrival counters are back at zero after every launch.  The first shape is split by
+    the launcher's own choice (narrow sampler conv), the others only when forced."""
+    import ctypes as C_
+    from nvae_tf_amd import _lib as L_
+    from nvae_tf_amd import ops
+    B, H, ci, co, k = shape
+    L_.ensure_workspace(dev)
+    slab, counters = L_._workspace["ws"]
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(B, H, H, ci, generator=g)
+    w = torch.randn(k, k, ci, co, generator=g) / (k * k * ci) ** 0.5
+    pad = (k - 1) // 2
+    y_ref = ref_conv(q(x, dtype), q(w, dtype), None, 1, (pad, pad), 1, (H, H))
+    xd = x.to(dev, dtype)
+    wT = w.permute(3, 0, 1, 2).reshape(co, k * k * ci).contiguous().to(dev, dtype)
+    geom = L_.ConvGeom(B, H, H, ci, H, H, co, k, k, 1, pad, pad, 1, 0, ci, co, co)
+    code = L_.dtype_code(dtype)
+    lib.nvae_conv_img_enable(0)
+    try:
+        outs = {}
+        for S in (1, 0, 2, 3, 5):                 # 1 = never split, 0 = the launcher's choice
+            lib.nvae_conv_gemm_force_split(S)
+            runs = []
+            for _ in range(3):
+                y = torch.full((B, H, H, co), float("nan"), device=dev, dtype=dtype)
+                L_.call("nvae_conv_gemm", code, C_.byref(geom), L_.ptr(xd), L_.ptr(wT), k * k * ci, None, None, L_.ptr(y), 0, None)
+                runs.append(y)
+            torch.cuda.synchronize()
+            assert int(counters.abs().sum()) == 0
+            assert torch.equal(runs[0], runs[1]) and torch.equal(runs[0], runs[2])
+            assert rel_err(runs[0], y_ref) < TOL[dtype], S
+            outs[S] = runs[0]
+        # a split changes the f32 summation order only
+        for S in (0, 2, 3, 5):
+            assert rel_err(outs[S], outs[1].double().cpu()) < (1e-5 if dtype == torch.float32 else TOL[dtype])
+    finally:
+        lib.nvae_conv_gemm_force_split(0)
+        lib.nvae_conv_img_enable(1)
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16", "f16"])
 def test_conv_channel_slices(lib, dev, dtype):
     """Concat-free DecoderSampleCombiner (row slices + accumulate) and SkipScaler (output slices)."""
     from nvae_tf_amd import ops
@@ -413,8 +459,8 @@ def test_fused_bn_chain(lib, dev, dtype, case, mode, monkeypatch):
 @pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16", "f16"])
 @pytest.mark.parametrize("shape", [(6, 4, 4, 256), (3, 8, 8, 72), (2, 16, 16, 64), (130, 4, 4, 128), (2, 32, 32, 32)])
 @pytest.mark.parametrize("lazy", [False, True], ids=["materialised", "lazy"])
-@pytest.mark.parametrize("se_path", ["fused", "strips"])
-def test_fused_bn_se_chain(lib, dev, dtype, shape, lazy, se_path, monkeypatch):
+@pytest.mark.parametrize("se_path", ["fused", "strips", "split4"])
+def test_fused_bn_se_chain(lib, dev, dtype, shape, lazy, se_path, monkeypatch, request):
     """BN -> SE + residual -> BN: the SE kernel emits the next BatchNorm's statistics, its backward apply
     reduces the previous BatchNorm's backward sums; both BatchNorms use the finalize-in-apply passes.
     lazy: the first BatchNorm is applied inside the fused SE kernels (forward and backward) from its
@@ -423,7 +469,9 @@ def test_fused_bn_se_chain(lib, dev, dtype, shape, lazy, se_path, monkeypatch):
     72 channels: not a power of two -> the unfused launch sequence.)  se_path: the one-launch kernels or the
     strip-structured three-kernel path (the default below ~100 images), both at every shape."""
     from nvae_tf_amd import ops
-    monkeypatch.setattr(ops, "SE_FUSED_MIN_B", 0 if se_path == "fused" else 10 ** 9)
+    monkeypatch.setattr(ops, "SE_FUSED_MIN_B", 10 ** 9 if se_path == "strips" else 0)
+    lib.nvae_se_force_split(4 if se_path == "split4" else 1)      # (image-split form of the fused kernels where legal)
+    request.addfinalizer(lambda: lib.nvae_se_force_split(-1))
     from nvae_tf_amd.ops import Var
     from nvae_tf_amd.params import ParamStore
     g = torch.Generator().manual_seed(31)
@@ -443,7 +491,7 @@ def test_fused_bn_se_chain(lib, dev, dtype, shape, lazy, se_path, monkeypatch):
         m, v = t.mean((0, 1, 2)), t.var((0, 1, 2), unbiased=False)
         return (t - m) * torch.rsqrt(v + 1e-5) * ga + be
     a = bn_ref(x64, P["bn1.gamma"], P["bn1.beta"])
-    really_lazy = lazy and C_ & (C_ - 1) == 0 and se_path == "fused"
+    really_lazy = lazy and C_ & (C_ - 1) == 0 and se_path != "strips"
     aq = a if really_lazy else q(a.detach().float(), dtype) + (a - a.detach())
     gate = torch.sigmoid(torch.relu(aq.mean((1, 2)) @ P["se.w1"] + P["se.b1"]) @ P["se.w2"] + P["se.b2"])
     r = 0.1 * s64 + aq * gate[:, None, None, :]
@@ -476,12 +524,15 @@ def test_fused_bn_se_chain(lib, dev, dtype, shape, lazy, se_path, monkeypatch):
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16", "f16"])
 @pytest.mark.parametrize("shape,ss,bs", [((3, 8, 8, 128), 0.1, 1.0), ((4, 4, 4, 256), 1.0, 0.1), ((2, 32, 32, 32), 1.0, 0.1)])
-@pytest.mark.parametrize("se_path", ["fused", "strips"])
-def test_se_residual(lib, dev, dtype, shape, ss, bs, se_path, monkeypatch):
+@pytest.mark.parametrize("se_path", ["fused", "strips", "split2", "split8"])
+def test_se_residual(lib, dev, dtype, shape, ss, bs, se_path, monkeypatch, request):
     from nvae_tf_amd import ops
-    # the one-launch kernels (whole images per workgroup) are the default from ~100 images up, the strip-structured
-    # three-kernel path below that: both at every shape here
-    monkeypatch.setattr(ops, "SE_FUSED_MIN_B", 0 if se_path == "fused" else 10 ** 9)
+    # the one-launch kernels (whole images per workgroup), the strip-structured three-kernel path, and the image-split
+    # form of the one-launch kernels (S workgroups per image with an in-kernel hand-off; where S is not legal for a
+    # shape the launcher falls back to whole images): all at every shape here
+    monkeypatch.setattr(ops, "SE_FUSED_MIN_B", 10 ** 9 if se_path == "strips" else 0)
+    lib.nvae_se_force_split(int(se_path[5:]) if se_path.startswith("split") else 1)
+    request.addfinalizer(lambda: lib.nvae_se_force_split(-1))
     from nvae_tf_amd.ops import Var
     from nvae_tf_amd.params import ParamStore
     g = torch.Generator().manual_seed(13)
@@ -509,6 +560,13 @@ def test_se_residual(lib, dev, dtype, shape, ss, bs, se_path, monkeypatch):
     assert rel_err(xv.g, gr[0]) < tol and rel_err(sv.g, gr[1]) < tol
     for i, n in enumerate(("w1", "b1", "w2", "b2")):
         assert rel_err(ps.get_grad("se." + n), gr[2 + i]) < 4 * tol, n
+    if se_path.startswith("split"):
+        from nvae_tf_amd import _lib as L_
+        torch.cuda.synchronize()
+        assert int(L_._workspace["se"][1].abs().sum()) == 0        # per-image hand-off counters back at rest
+        # the slice-ordered sums make the forward result independent of which slice arrives last
+        y2 = ops.se_residual(make_ctx(ps, dtype, record=False), Var(x.to(dev, dtype)), se, Var(skip.to(dev, dtype)), ss, bs)
+        assert torch.equal(y.t, y2.t)
 
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16", "f16"])
