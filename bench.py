@@ -323,11 +323,12 @@ def side_workload(args):
     print(json.dumps(res))
 
 
-def time_dp_configured(args, device, dtype, x, plain_ms):
+def time_dp_configured(args, device, dtype, x, plain_step):
     """The step as ONE data-parallel rank runs it, on one GPU: GradReducer(force=True) over a single-rank RCCL group
     (every collective is issued and runs through RCCL's kernels on its own stream), backward cut into the DP
     segments, each its own hipGraph, bucketed asynchronous all-reduce after each.  What it cannot show is the
-    xGMI transfer time itself; what it does show is everything a rank pays before any byte moves."""
+    xGMI transfer time itself; what it does show is everything a rank pays before any byte moves.  Plain and
+    DP-configured steps are timed in interleaved rounds in this one process (cdna guide rule 24); medians reported."""
     import torch.distributed as dist
     from nvae_tf_amd import parallel
     own_group = not dist.is_initialized()
@@ -342,17 +343,28 @@ def time_dp_configured(args, device, dtype, x, plain_ms):
         m.reducer = parallel.GradReducer(force=True)
         m.capture_train_step(x.shape, warmup=1)
         m._static_x.copy_(x.to(dtype))
+        dp_step = lambda: m.train_step_graphed(None)
+
+        def timed(fn, n):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                out = fn()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0) / n * 1e3, out
         for _ in range(args.warmup):
-            m.train_step_graphed(None)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            out = m.train_step_graphed(None)
-        torch.cuda.synchronize()
-        ms = (time.perf_counter() - t0) / args.steps * 1e3
-        segs = [m.grad_range(k) for k in range(m.n_segments())]
-        return {"ms_per_step": ms, "plain_ms_per_step": plain_ms, "dp_overhead_ms": ms - plain_ms,
-                "ratio": ms / plain_ms, "backward_segments": len(segs),
+            dp_step()
+        rounds, n = 5, max(args.steps // 2, 4)
+        plain, dp = [], []
+        for _ in range(rounds):
+            plain.append(timed(plain_step, n)[0])
+            t, out = timed(dp_step, n)
+            dp.append(t)
+        med = lambda v: sorted(v)[len(v) // 2]
+        segs = [m.grad_range(k) for k in range(m.n_segments())] if m._dp_segments() else [(0, int(m.ps.grads.numel()))]
+        return {"ms_per_step": med(dp), "plain_ms_per_step": med(plain), "dp_overhead_ms": med(dp) - med(plain),
+                "ratio": med(dp) / med(plain), "rounds_ms": {"plain": [round(v, 3) for v in plain], "dp": [round(v, 3) for v in dp]},
+                "backward_segments": len(segs),
                 "segment_gradient_mbytes": [round((hi - lo) * 4 / 1e6, 1) for lo, hi in segs],
                 "allreduce_bytes_per_step": int(m.ps.grads.numel()) * 4, "loss_nats": float(out["loss"]),
                 "collectives": "single-rank RCCL (ReduceOp.AVG), 64 MB buckets, asynchronous per segment"}
@@ -437,7 +449,7 @@ def main():
 
     dp_cfg = None
     if args.force_dp and world == 1:
-        dp_cfg = time_dp_configured(args, device, dtype, x, dt / args.steps * 1e3)
+        dp_cfg = time_dp_configured(args, device, dtype, x, step)
     if rank == 0:
         value = args.batch * world * args.steps / dt
         kern = time_dominant_kernel(model, args.batch)

@@ -394,6 +394,27 @@ int nvae_sampler_fwd(int dtype, const float* enc_p, const float* dec_p, const fl
 int nvae_sampler_bwd(int dtype, const float* enc_p, const float* dec_p, const float* eps,
                      const void* dz, const float* coeff, const float* hyper, float inv_batch,
                      void* d_enc, void* d_dec, int B, int HW, int L, void* stream);
+/* nvae_sampler_bwd when dz carries a range-normalisation tag (below): the KL seed is multiplied by 2^gscales[gid] so that
+ * both terms of the output share dz's exponent.  gscales NULL: plain.                                       */
+int nvae_sampler_bwd_scaled(int dtype, const float* enc_p, const float* dec_p, const float* eps, const void* dz,
+                            const float* coeff, const float* hyper, float inv_batch, void* d_enc, void* d_dec, int B,
+                            int HW, int L, const float* gscales, int gid, void* stream);
+/* ---- activation-gradient range normalisation (float16 activations on deep hierarchies: BASELINE.json configs[4]) ----
+ * Gradients of a 40-group NVAE span 19 decades at initialisation, float16 holds 12: the backward pass renormalises the
+ * activation gradient at latent-group boundaries ON THE DEVICE.  `scales` is a zeroed per-step float array; entry id holds
+ * the cumulative log2 factor of every gradient tagged id (entry 0 stays 0 = untouched).
+ *   nvae_grad_amax:    slot[0] = max(slot[0], max |g|)                         (slot ZEROED per step)
+ *   nvae_grad_rescale: g *= 2^k in place, k = floor(target_log2 - log2 amax) clamped to +-40; scales[id_out] = scales[id_in] + k
+ *   nvae_grad_merge:   dst = dst * 2^(m - scales[id_dst]) + src * 2^(m - scales[id_src]), m = min of the two; scales[id_out] = m
+ *   nvae_grad_unscale: grads[4*off .. 4*(off + count)) *= 2^-scales[id] for each table row (off, count, id, 0), in float4 units:
+ *                      parameter gradients are f32 and were written with their dy's tag                       */
+int nvae_grad_amax(int dtype, const void* g, long n, float* slot, void* stream);
+int nvae_grad_rescale(int dtype, void* g, long n, const float* amax, float* scales, int id_in, int id_out,
+                      float target_log2, void* stream);
+int nvae_grad_merge(int dtype, void* dst, const void* src, long n, float* scales, int id_dst, int id_src, int id_out,
+                    void* stream);
+int nvae_grad_unscale(float* grads, const int* table /*device [n_ranges][4]*/, int n_ranges, const float* scales,
+                      void* stream);
 
 /* ---- Bernoulli reconstruction, models.py:242-250: recon[b] = sum softplus(l) - x*l;
  *      crop != 0 restricts to rows/cols [2, H-2) (evaluate.py:117).  logits f32, x dtype.        */

@@ -124,6 +124,11 @@ _SIGS = {
     "nvae_randn": [_p, _l, C.c_ulonglong, _p],
     "nvae_sampler_fwd": [_i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i],
     "nvae_sampler_bwd": [_i, _p, _p, _p, _p, _p, _p, _f, _p, _p, _i, _i, _i],
+    "nvae_sampler_bwd_scaled": [_i, _p, _p, _p, _p, _p, _p, _f, _p, _p, _i, _i, _i, _p, _i],
+    "nvae_grad_amax": [_i, _p, _l, _p],
+    "nvae_grad_rescale": [_i, _p, _l, _p, _p, _i, _i, _f],
+    "nvae_grad_merge": [_i, _p, _p, _l, _p, _i, _i, _i],
+    "nvae_grad_unscale": [_p, _p, _i, _p],
     "nvae_bernoulli_fwd": [_i, _p, _p, _p, _i, _i, _i, _i, _i],
     "nvae_bernoulli_bwd": [_i, _p, _p, _p, _l, _f, _p],
     "nvae_dmol_fwd": [_p, _i, _p, _p, _i, _i, _i],

@@ -191,6 +191,108 @@ extern "C" int nvae_loss_scale_update(float* hyper, float min_scale, float max_s
     return NVAE_OK;
 }
 
+// ---- activation-gradient range normalisation (float16 path, deep hierarchies) ---------------------------------
+// At a random initialisation the gradients of a 30-40-group NVAE grow by ~1.5-2x per latent group on the way back: 19
+// decades from the last decoder group to the stem at C5 (profiles/r02_f16_gradient_range_c5.txt), against float16's 12
+// including subnormals, so NO single loss scale fits.  The backward pass therefore renormalises the activation
+// gradient at group boundaries, entirely on the device (nothing here needs the host, so it lives inside the captured
+// graphs): k_grad_amax finds max |g| of the tensor, k_grad_rescale multiplies it by the power of two that brings that
+// maximum to 2^target and records the CUMULATIVE exponent under a new scale id (`scales[id]` = log2 of the factor that
+// every gradient tagged with that id carries on top of the loss scale).  Linear backward ops hand the tag on; two
+// gradients with different tags are added by k_grad_merge on the smaller of the two exponents (no overflow); parameter
+// gradients (f32, written with their dy's tag) are divided by it at the end (k_grad_unscale).
+template <typename T>
+__global__ void k_grad_amax(const T* __restrict__ g, long n8, float* __restrict__ slot) {
+    float m = 0.f;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n8; i += gridDim.x * 256L) {
+        float v[8];
+        V8<T>::ld(g + i * 8, v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) m = fmaxf(m, fabsf(v[j]));      // (fmaxf drops NaNs; infinities survive)
+    }
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) atomicMax((unsigned*)slot, __float_as_uint(m));      // non-negative floats order like uints
+}
+__device__ __forceinline__ float pow2i(float e) { return __uint_as_float((unsigned)((int)e + 127) << 23); }   // e in [-126, 127]
+template <typename T>
+__global__ void k_grad_rescale(T* __restrict__ g, long n8, const float* __restrict__ amax, float* __restrict__ scales,
+                               int id_in, int id_out, float target_log2) {
+    const float a = amax[0];
+    float k = 0.f;
+    if (a > 0.f && a < 3.0e38f) k = fminf(fmaxf(floorf(target_log2 - log2f(a)), -40.f), 40.f);
+    if (blockIdx.x == 0 && threadIdx.x == 0) scales[id_out] = scales[id_in] + k;
+    if (k == 0.f) return;
+    const float f = pow2i(k);
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n8; i += gridDim.x * 256L) {
+        float v[8];
+        V8<T>::ld(g + i * 8, v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] *= f;
+        V8<T>::st(g + i * 8, v);
+    }
+}
+template <typename T>
+__global__ void k_grad_merge(T* __restrict__ dst, const T* __restrict__ src, long n8, float* __restrict__ scales,
+                             int id_dst, int id_src, int id_out) {
+    const float sd = scales[id_dst], ss = scales[id_src];
+    const float m = fminf(sd, ss);
+    const float fd = pow2i(fmaxf(m - sd, -120.f)), fs = pow2i(fmaxf(m - ss, -120.f));
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n8; i += gridDim.x * 256L) {
+        float a[8], b[8];
+        V8<T>::ld(dst + i * 8, a);
+        V8<T>::ld(src + i * 8, b);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a[j] = a[j] * fd + b[j] * fs;
+        V8<T>::st(dst + i * 8, a);
+    }
+    // (every block read both exponents before anybody may overwrite one of them: id_out is a fresh id)
+    if (blockIdx.x == 0 && threadIdx.x == 0) scales[id_out] = m;
+}
+// table: [n_ranges][4] ints = (offset / 4, float4 count, scale id, unused); one row of workgroups per range
+__global__ void k_grad_unscale(float* __restrict__ grads, const int* __restrict__ table, const float* __restrict__ scales) {
+    const int* r = table + 4 * blockIdx.y;
+    const float e = -scales[r[2]];
+    if (e == 0.f) return;
+    // exponents beyond a float's range are applied in two steps
+    const float f1 = pow2i(fminf(fmaxf(e, -100.f), 100.f)), f2 = pow2i(fminf(fmaxf(e - fminf(fmaxf(e, -100.f), 100.f), -100.f), 100.f));
+    float4* p = (float4*)grads + r[0];
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < r[1]; i += gridDim.x * 256) {
+        float4 v = p[i];
+        v.x = v.x * f1 * f2; v.y = v.y * f1 * f2; v.z = v.z * f1 * f2; v.w = v.w * f1 * f2;
+        p[i] = v;
+    }
+}
+extern "C" int nvae_grad_amax(int dtype, const void* g, long n, float* slot, void* stream) {
+    NVAE_REQUIRE(n > 0 && n % 8 == 0 && g && slot && aligned16(g), "grad_amax: bad args (n=%ld)", n);
+    DISPATCH_T(dtype, hipLaunchKernelGGL((k_grad_amax<T>), ew_grid(n / 8), 256, 0, (hipStream_t)stream, (const T*)g, n / 8, slot);)
+    NVAE_LAUNCH_CHECK("grad_amax");
+    return NVAE_OK;
+}
+extern "C" int nvae_grad_rescale(int dtype, void* g, long n, const float* amax, float* scales, int id_in, int id_out,
+                                 float target_log2, void* stream) {
+    NVAE_REQUIRE(n > 0 && n % 8 == 0 && g && amax && scales && aligned16(g) && id_in >= 0 && id_out > 0 && id_in != id_out,
+                 "grad_rescale: bad args (n=%ld, ids %d -> %d)", n, id_in, id_out);
+    DISPATCH_T(dtype, hipLaunchKernelGGL((k_grad_rescale<T>), ew_grid(n / 8), 256, 0, (hipStream_t)stream, (T*)g, n / 8, amax,
+                                         scales, id_in, id_out, target_log2);)
+    NVAE_LAUNCH_CHECK("grad_rescale");
+    return NVAE_OK;
+}
+extern "C" int nvae_grad_merge(int dtype, void* dst, const void* src, long n, float* scales, int id_dst, int id_src,
+                               int id_out, void* stream) {
+    NVAE_REQUIRE(n > 0 && n % 8 == 0 && dst && src && scales && aligned16(dst) && aligned16(src) && id_out > 0 &&
+                 id_out != id_dst && id_out != id_src, "grad_merge: bad args (n=%ld, ids %d + %d -> %d)", n, id_dst, id_src, id_out);
+    DISPATCH_T(dtype, hipLaunchKernelGGL((k_grad_merge<T>), ew_grid(n / 8), 256, 0, (hipStream_t)stream, (T*)dst, (const T*)src,
+                                         n / 8, scales, id_dst, id_src, id_out);)
+    NVAE_LAUNCH_CHECK("grad_merge");
+    return NVAE_OK;
+}
+extern "C" int nvae_grad_unscale(float* grads, const int* table, int n_ranges, const float* scales, void* stream) {
+    NVAE_REQUIRE(grads && table && scales && n_ranges > 0 && aligned16(grads), "grad_unscale: bad args");
+    hipLaunchKernelGGL(k_grad_unscale, dim3(64, n_ranges), 256, 0, (hipStream_t)stream, grads, table, scales);
+    NVAE_LAUNCH_CHECK("grad_unscale");
+    return NVAE_OK;
+}
+
 extern "C" int nvae_unary_fwd(int dtype, int op, const void* x, void* y, long n, float a, float b,
                               void* stream) {
     NVAE_REQUIRE(n > 0 && n % 8 == 0, "unary_fwd: n=%ld must be a positive multiple of 8", n);

@@ -77,8 +77,11 @@ __global__ void k_sampler_bwd(const float* __restrict__ enc_p, const float* __re
                               const float* __restrict__ eps, const T* __restrict__ dz,
                               const float* __restrict__ coeff, const float* __restrict__ hyper,
                               float inv_batch, T* __restrict__ d_enc, T* __restrict__ d_dec, int L,
-                              long n) {
+                              long n, const float* __restrict__ gscales, int gid) {
     inv_batch *= loss_scale_of(hyper);
+    // dz arrives range-normalised (elementwise.hip "activation-gradient range normalisation"): the KL seed joins it on
+    // the same exponent
+    if (gscales) inv_batch *= exp2f(gscales[gid]);
     const float ckl = hyper[NVAE_HY_BETA] * coeff[0] * inv_batch;
     for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += gridDim.x * 256L) {
         long pix = i / L;
@@ -112,17 +115,24 @@ __global__ void k_sampler_bwd(const float* __restrict__ enc_p, const float* __re
     }
 }
 
-extern "C" int nvae_sampler_bwd(int dtype, const float* enc_p, const float* dec_p, const float* eps,
-                                const void* dz, const float* coeff, const float* hyper, float inv_batch,
-                                void* d_enc, void* d_dec, int B, int HW, int L, void* stream) {
+extern "C" int nvae_sampler_bwd_scaled(int dtype, const float* enc_p, const float* dec_p, const float* eps,
+                                       const void* dz, const float* coeff, const float* hyper, float inv_batch,
+                                       void* d_enc, void* d_dec, int B, int HW, int L, const float* gscales, int gid,
+                                       void* stream) {
     NVAE_REQUIRE(B > 0 && HW > 0 && L > 0 && enc_p && eps && coeff && hyper && d_enc, "sampler_bwd: bad args");
     NVAE_REQUIRE((dec_p == nullptr) == (d_dec == nullptr), "sampler_bwd: dec_p/d_dec mismatch");
     long n = (long)B * HW * L;
     long g = (n + 255) / 256;
     if (g > 2048) g = 2048;
-    DISPATCH_T(dtype, hipLaunchKernelGGL((k_sampler_bwd<T>), (int)g, 256, 0, (hipStream_t)stream, enc_p, dec_p, eps, (const T*)dz, coeff, hyper, inv_batch, (T*)d_enc, (T*)d_dec, L, n);)
+    DISPATCH_T(dtype, hipLaunchKernelGGL((k_sampler_bwd<T>), (int)g, 256, 0, (hipStream_t)stream, enc_p, dec_p, eps, (const T*)dz, coeff, hyper, inv_batch, (T*)d_enc, (T*)d_dec, L, n, gscales, gid);)
     NVAE_LAUNCH_CHECK("sampler_bwd");
     return NVAE_OK;
+}
+extern "C" int nvae_sampler_bwd(int dtype, const float* enc_p, const float* dec_p, const float* eps,
+                                const void* dz, const float* coeff, const float* hyper, float inv_batch,
+                                void* d_enc, void* d_dec, int B, int HW, int L, void* stream) {
+    return nvae_sampler_bwd_scaled(dtype, enc_p, dec_p, eps, dz, coeff, hyper, inv_batch, d_enc, d_dec, B, HW, L, nullptr, 0,
+                                   stream);
 }
 
 // models.py:242-250; one block per image

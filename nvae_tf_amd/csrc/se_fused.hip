@@ -574,8 +574,10 @@ static int sef_split(int B, int HW, int C) {
     // worth it when one workgroup per image leaves most of the chip idle and an image is big enough to pay for the
     // hand-off (measured: profiles/r03_se_split.txt)
     if (B > 64 || (long)HW * C < 32768) return 1;
+    // slices of >= 16 K elements (32 KB of 16-bit data): below that the hand-off costs more than the extra workgroups buy
+    // (tools/mb_se.py: 16x16x256 at batch 32 runs 24 / 36 us whole, 18 / 24 us in 4 slices, 24 / 26 us in 8)
     int S = 1;
-    while (legal(2 * S)) S *= 2;
+    while (legal(2 * S) && (long)(HW / (2 * S)) * C >= 16384) S *= 2;
     return S;
 }
 

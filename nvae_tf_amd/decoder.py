@@ -100,6 +100,8 @@ class Decoder:
         L.call("nvae_cast", L.F32, ctx.dt, L.ptr(src), L.ptr(out.t), src.numel())
         if ctx.record:
             def bwd():
+                if ctx.gs is not None:
+                    ctx.gs.note(self.h, out.gid)
                 if out.g is not None:
                     # dh[c'] = sum_b dH[b, c']: column sum over the batch with c' = (h,w,c) flattened
                     L.call("nvae_colsum", ctx.dt, L.ptr(out.g), batch, hh * hw * d, hh * hw * d,
@@ -120,6 +122,7 @@ class Decoder:
         combine_idx = 0
         for group in self.groups[1:]:
             if isinstance(group, DecoderSampleCombiner):
+                x = ops.grad_boundary(ctx, x)      # (float16 on deep hierarchies: renormalise the gradient per latent group)
                 enc_prior = enc_dec_combiners[combine_idx](x)
                 zi = combine_idx + 1
                 z = self.sampler(ctx, x, zi, eps_list[zi], kl_all[zi], coeff[zi:zi + 1], hyper, inv_batch,

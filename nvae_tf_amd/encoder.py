@@ -83,8 +83,10 @@ class Encoder:
             if isinstance(group, EncoderDecoderCombiner):
                 enc_dec_combiners.append(partial(group, ctx, x))   # evaluated later by the decoder
             elif isinstance(group, list):
+                xb = ops.grad_boundary(ctx, x)     # (float16 on deep hierarchies; the combiner tap keeps the unwrapped x)
                 for cell in group:
-                    x = cell(ctx, x)
+                    xb = cell(ctx, xb)
+                x = xb
             else:
                 x = group(ctx, x)
         # final_enc: ELU -> SN conv1x1 -> ELU, encoder.py:58-66

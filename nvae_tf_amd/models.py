@@ -141,6 +141,12 @@ class NVAE:
         # tf_literal=True reproduces that; the default is the author-intended training semantics.
         self.tf_literal = False
         self._side = None
+        # float16 activations on a deep hierarchy: the backward pass renormalises the activation gradient at every
+        # latent-group / cell boundary on the device (ops.GradScale; BASELINE.json configs[4] names fp16 for the 40-group
+        # CelebA-64 model, whose gradients span 19 decades at initialisation against float16's 12).  NVAE_GRAD_RESCALE=0/1
+        # overrides; default: float16 with more than 16 latent groups.
+        env = os.environ.get("NVAE_GRAD_RESCALE")
+        self.grad_rescale = (dtype == torch.float16 and self.n_groups > 16) if env is None else (env != "0" and dtype != torch.float32)
 
     # ------------------------------------------------------------------ helpers
     def n_trainable(self) -> int:
@@ -356,6 +362,8 @@ class NVAE:
         ctx = Ctx(ps, self.dtype, training=not self.tf_literal, record=True,
                   side_stream=self._side if self.overlap_wgrad else None)
         ctx.dw_pre = self.reducer is None or DP_DW_PRE
+        if self.grad_rescale:
+            ctx.gs = ops.GradScale(ctx)
         self._bn_loss = ctx.zeros_f32(1)
         nb = len(ps.bn_loss_layers)
         if nb:
@@ -413,14 +421,26 @@ class NVAE:
                    B, L.ptr(buf["recon"]), L.ptr(self._bn_loss), L.ptr(self.hyper), L.ptr(self.coeff),
                    L.ptr(buf["kl_loss"]), L.ptr(self.results))
             nb = len(ps.bn_loss_layers)
-            if nb:      # subgradient of the BN regulariser: depends on the parameters only, so it goes first
+            if nb and ctx.gs is None:      # subgradient of the BN regulariser: depends on the parameters only, so it goes first
                 L.call("nvae_bn_absmax_bwd", L.ptr(ps.params), L.ptr(ps.grads), L.ptr(ps.bn_table),
                        L.ptr(ps.bn_argmax), nb, float(self.sr_lambda), L.ptr(self.hyper))
         if part is None:
             ctx.backward()
+            glo, ghi = 0, ps.grads.numel()
         else:
             lo, hi = self._segments[part][:2]
             ctx.backward(lo, hi if part else None, join=join)      # (the loss ops appended after the forward pass belong to segment 0)
+            glo, ghi = self.grad_range(part)
+        if ctx.gs is not None:
+            # range-normalised backward pass: the parameter gradients of this range carry their dy's power-of-two tag until
+            # here; the regulariser's subgradient (true scale) is added afterwards, for the layers of this range
+            assert join, "GradScale.unscale needs the weight-gradient kernels joined"
+            ctx.gs.unscale(glo, ghi)
+            rows = [i for i, b in enumerate(ps.bn_loss_layers) if glo <= b.gamma.off < ghi]
+            if rows:
+                assert rows == list(range(rows[0], rows[-1] + 1))
+                L.call("nvae_bn_absmax_bwd", L.ptr(ps.params), L.ptr(ps.grads), L.ptr(ps.bn_table) + 8 * rows[0],
+                       L.ptr(ps.bn_argmax) + 4 * rows[0], len(rows), float(self.sr_lambda), L.ptr(self.hyper))
 
     def grad_range(self, part: int):
         """Flat gradient range completed by backward segment `part` (see _make_segments)."""

@@ -27,11 +27,12 @@ class Var:
     coefficient table; consumers that can apply the BatchNorm themselves (conv2d's operand prologue, the fused
     SE kernels) read `raw` + `pre.coef()`, everybody else reads `t`, which materialises the normalised
     activation on first use (one apply launch, as in round 1)."""
-    __slots__ = ("_t", "g", "needs_grad", "stats", "uses", "bn_src", "pre", "fin")
+    __slots__ = ("_t", "g", "needs_grad", "stats", "uses", "bn_src", "pre", "fin", "gid")
 
     def __init__(self, t: torch.Tensor, needs_grad: bool = True):
         self._t = t
         self.g: Optional[torch.Tensor] = None
+        self.gid = 0        # range-normalisation tag of .g (GradScale): .g = 2^scales[gid] x the (loss-scaled) gradient
         self.needs_grad = needs_grad
         self.stats = None   # (slab [S,2,C] f32, S): BN statistics partials emitted by the producing kernel
         self.fin = None     # (bn, coef [4,C]): the producing kernel also finalized THAT BatchNorm's coefficients
@@ -76,6 +77,89 @@ DW_PRE = os.environ.get("NVAE_DW_PRE", "1") != "0"           # BN(+Swish) in fro
 BN_BWD_SPLIT = os.environ.get("NVAE_BN_BWD_SPLIT", "0") != "0"  # unfused BN backward: reduce + self-finishing apply
 
 
+GRAD_TARGET_LOG2 = float(os.environ.get("NVAE_GRAD_TARGET_LOG2", "6"))   # renormalised activation gradients peak at 2^6
+
+
+class GradScale:
+    """Device-side range normalisation of the activation gradients (float16 activations on deep hierarchies; kernels and
+    rationale: csrc/elementwise.hip).  `grad_boundary` ops renormalise the gradient that crosses them and give it a new
+    tag; every backward closure hands its output gradient's tag (Var.gid) to the gradients it produces; gradients with
+    different tags are merged on the smaller exponent; parameter gradients are recorded with the tag of the dy they were
+    computed from and divided by 2^scales[tag] after the backward pass (`unscale`).  Nothing here reads device memory
+    on the host, so the whole scheme is captured into the step's hipGraphs."""
+
+    MAX_IDS = 2048
+
+    def __init__(self, ctx: "Ctx"):
+        self.ctx = ctx
+        self.scales = ctx.zeros_f32(self.MAX_IDS)        # zeroed with the per-step pool; entry 0 stays 0
+        self.amax = ctx.zeros_f32(self.MAX_IDS)
+        self.next_id = 1
+        self.ranges: List[Tuple[int, int, int]] = []     # (flat parameter offset, numel, tag) of gradients written so far
+        self.pending: List[tuple] = []                   # (var, temporary gradient, its tag): merged after the closure
+
+    def new_id(self) -> int:
+        i = self.next_id
+        if i >= self.MAX_IDS:
+            raise RuntimeError("GradScale: out of scale ids")
+        self.next_id += 1
+        return i
+
+    def note(self, slot, gid: int):
+        """A parameter gradient (params.Slot) was / will be accumulated from a dy tagged gid."""
+        if slot is not None:
+            self.ranges.append((slot.off, slot.numel, gid))
+
+    def merge(self, v: "Var", src: torch.Tensor, src_id: int):
+        nid = self.new_id()
+        call("nvae_grad_merge", self.ctx.dt, ptr(v.g), ptr(src), src.numel(), ptr(self.scales), v.gid, src_id, nid)
+        v.gid = nid
+
+    def flush(self):
+        for v, tmp, gid in self.pending:
+            self.merge(v, tmp, gid)
+        self.pending.clear()
+
+    def rescale(self, g: torch.Tensor, gid: int) -> int:
+        """Renormalise g in place; returns its new tag."""
+        nid = self.new_id()
+        slot = ptr(self.amax) + 4 * nid
+        call("nvae_grad_amax", self.ctx.dt, ptr(g), g.numel(), slot)
+        call("nvae_grad_rescale", self.ctx.dt, ptr(g), g.numel(), slot, ptr(self.scales), gid, nid, GRAD_TARGET_LOG2)
+        return nid
+
+    def unscale(self, lo: int = 0, hi: Optional[int] = None):
+        """Divide the parameter gradients recorded so far (those inside [lo, hi) of the flat buffer) by their tags' factors
+        and forget them.  Call after the weight-gradient kernels have been joined."""
+        ps = self.ctx.ps
+        hi = ps.grads.numel() if hi is None else hi
+        keep, by_off = [], {}
+        for off, n, gid in self.ranges:
+            if lo <= off < hi:
+                n8 = (n + 7) // 8 * 8                               # (slots are padded to 8 floats: params.ALIGN)
+                assert by_off.setdefault(off, (n8, gid)) == (n8, gid), "one parameter, two gradient tags"
+            else:
+                keep.append((off, n, gid))
+        self.ranges = keep
+        merged = []
+        for off in sorted(by_off):
+            n, gid = by_off[off]
+            if not gid:
+                continue
+            if merged and merged[-1][2] == gid and merged[-1][0] + merged[-1][1] == off:
+                merged[-1] = (merged[-1][0], merged[-1][1] + n, gid)
+            else:
+                merged.append((off, n, gid))
+        if not merged:
+            return
+        key = tuple(merged)
+        cache = ps.__dict__.setdefault("_unscale_tables", {})
+        if key not in cache:
+            flat = [v for off, n, gid in merged for v in (off // 4, n // 4, gid, 0)]
+            cache[key] = torch.tensor(flat, dtype=torch.int32, device=ps.grads.device)
+        call("nvae_grad_unscale", ptr(ps.grads), ptr(cache[key]), len(merged), ptr(self.scales))
+
+
 class Ctx:
     """Per-step execution context: dtype, mode, tape, and the per-step zeroed f32 scratch pool."""
 
@@ -105,6 +189,7 @@ class Ctx:
         self.zero_pool = ps.zero_pool
         self._counters = None
         self.zero_cursor = ps.zero_reserved
+        self.gs: Optional[GradScale] = None     # set by the model for float16 runs of deep hierarchies
 
     # ---- memory -------------------------------------------------------------------------
     def empty(self, shape, dtype=None) -> torch.Tensor:
@@ -141,12 +226,20 @@ class Ctx:
             self._counters = self.zeros_f32(256)
         return ptr(self._counters)
 
-    def grad_of(self, v: Var) -> Tuple[torch.Tensor, int]:
-        """Gradient buffer of v and whether the next writer must accumulate into it."""
+    def grad_of(self, v: Var, gid: int = 0) -> Tuple[torch.Tensor, int]:
+        """Gradient buffer of v and whether the next writer must accumulate into it.  gid: range-normalisation tag of
+        the gradient about to be written (GradScale); a tag other than the buffer's sends the writer to a temporary that
+        is merged in after the current backward closure."""
         if v.g is None:
             v.g = torch.empty(v.shape, dtype=self.dtype, device=self.dev)
+            v.gid = gid
             return v.g, 0
-        return v.g, 1
+        if v.gid == gid:
+            return v.g, 1
+        assert self.gs is not None, "gradient tags without a GradScale"
+        tmp = torch.empty(v.shape, dtype=self.dtype, device=self.dev)
+        self.gs.pending.append((v, tmp, gid))
+        return tmp, 0
 
     def side_launch(self, fn: Callable[[], None], *keep):
         """Enqueue independent gradient work after everything issued so far, off the main stream.
@@ -246,8 +339,13 @@ class Ctx:
         join=False leaves the queued side-stream work forked (the caller continues on the side stream with
         `fork` and joins once at the end with `join_side`)."""
         hi = len(self.tape) if hi is None else hi
-        for fn in reversed(self.tape[lo:hi]):
-            fn()
+        if self.gs is None:
+            for fn in reversed(self.tape[lo:hi]):
+                fn()
+        else:
+            for fn in reversed(self.tape[lo:hi]):
+                fn()
+                self.gs.flush()
         self.flush_side()
         if join:
             self.join_side()
@@ -287,14 +385,35 @@ def unary(ctx: Ctx, x: Var, op: int) -> Var:
     call("nvae_unary_fwd", ctx.dt, op, ptr(x.t), ptr(y.t), x.t.numel(), 0.0, 0.0)
     if ctx.record and x.needs_grad:
         def bwd():
-            g, acc = ctx.grad_of(x)
+            g, acc = ctx.grad_of(x, y.gid)
             call("nvae_unary_bwd", ctx.dt, op, ptr(x.t), ptr(y.g), ptr(g), x.t.numel(), acc)
         ctx.tape.append(bwd)
     return y
 
 
-def add_grad(ctx: Ctx, dst: Var, src_grad: torch.Tensor):
-    g, acc = ctx.grad_of(dst)
+def grad_boundary(ctx: Ctx, x: Var) -> Var:
+    """Identity in the forward pass; in the backward pass the gradient that crosses it is renormalised to a fixed
+    range and retagged (GradScale).  Placed between latent groups / cells by the towers when ctx.gs is set."""
+    if ctx.gs is None or not ctx.record or not x.needs_grad:
+        return x
+    x.uses += 1
+    y = Var(x.t, True)
+    y.stats, y.fin = x.stats, x.fin
+
+    def bwd():
+        if y.g is None:
+            return
+        nid = ctx.gs.rescale(y.g, y.gid)
+        if x.g is None:
+            x.g, x.gid = y.g, nid
+        else:
+            ctx.gs.merge(x, y.g, nid)
+    ctx.tape.append(bwd)
+    return y
+
+
+def add_grad(ctx: Ctx, dst: Var, src_grad: torch.Tensor, gid: int = 0):
+    g, acc = ctx.grad_of(dst, gid)
     call("nvae_add", ctx.dt, ptr(g), ptr(src_grad), src_grad.numel(), acc)
 
 
@@ -402,6 +521,10 @@ def conv2d(ctx: Ctx, x: Var, conv, *, stride: int = 1, up: int = 1, pad: Optiona
             # ---- weight / bias gradient
             dw = ptr(ps.grads) + (conv.w.off + c_off * cout) * 4
             db = (ptr(ps.grads) + conv.b.off * 4) if (bias and conv.b is not None) else None
+            gid = out.gid
+            if ctx.gs is not None:
+                ctx.gs.note(conv.w, gid)
+                ctx.gs.note(conv.b if (bias and conv.b is not None) else None, gid)
             gw = _geom(B, H, W, cin, Ho, Wo, cout, k, k, stride, pad[0], pad[1], up, 0, Cx, Cy, Cy)
             w_mfma = (cin % ve == 0 and Cx % ve == 0 and cout % ve == 0 and Cy % ve == 0
                       and out_coff % ve == 0)
@@ -412,11 +535,11 @@ def conv2d(ctx: Ctx, x: Var, conv, *, stride: int = 1, up: int = 1, pad: Optiona
                                              cout, db), dy)
             # ---- residual
             if residual is not None and residual.needs_grad:
-                add_grad(ctx, residual, dy)
+                add_grad(ctx, residual, dy, gid)
             # ---- data gradient
             if x.needs_grad:
                 if up == 1:
-                    dst, acc = ctx.grad_of(x)
+                    dst, acc = ctx.grad_of(x, gid)
                 else:
                     dst, acc = ctx.empty((B, Hu, Wu, Cx)), 0
                     assert cin == Cx
@@ -453,7 +576,7 @@ def conv2d(ctx: Ctx, x: Var, conv, *, stride: int = 1, up: int = 1, pad: Optiona
                     call("nvae_conv_direct", ctx.dt, C.byref(gd), dy_ptr, w, conv.cin * cout, 1, cout, 1,
                          None, resid, ptr(dst), 0)
                 if up != 1:
-                    gx, accx = ctx.grad_of(x)
+                    gx, accx = ctx.grad_of(x, gid)
                     call("nvae_upsample_pool_bwd", ctx.dt, ptr(dst), ptr(gx), B, H, W, Cx, up, accx)
         ctx.tape.append(bwd)
     return out
@@ -488,6 +611,8 @@ def dwconv5(ctx: Ctx, x: Var, dw, want_stats: bool = False) -> Var:
             call("nvae_dwconv5", ctx.dt, ptr(xt), ptr(ps.view(dw.w)), ptr(ps.view(dw.b)), ptr(y.t), B, H, W, Cc, 0, 0)
     if ctx.record:
         def bwd():
+            if ctx.gs is not None:
+                ctx.gs.note(dw.w, y.gid); ctx.gs.note(dw.b, y.gid)
             if lazy_in:
                 ctx.side_launch(lambda: call("nvae_dwconv5_wgrad_pre", ctx.dt, ptr(xt), pre.scale, pre.shift, pre.act,
                                              ptr(y.g), ptr(ps.grads) + dw.w.off * 4, ptr(ps.grads) + dw.b.off * 4,
@@ -495,7 +620,7 @@ def dwconv5(ctx: Ctx, x: Var, dw, want_stats: bool = False) -> Var:
             else:
                 ctx.side_launch(lambda: call("nvae_dwconv5_wgrad", ctx.dt, ptr(xt), ptr(y.g), ptr(ps.grads) + dw.w.off * 4,
                                              ptr(ps.grads) + dw.b.off * 4, B, H, W, Cc), y.g)
-            g, acc = ctx.grad_of(x)
+            g, acc = ctx.grad_of(x, y.gid)
             call("nvae_dwconv5", ctx.dt, ptr(y.g), ptr(ps.view(dw.w)), None, ptr(g), B, H, W, Cc, 1, acc)
         ctx.tape.append(bwd)
     return y
@@ -626,10 +751,12 @@ def bn_act(ctx: Ctx, x: Var, bn, act: int = L.ACT_NONE, lazy: bool = True) -> Va
         y.bn_src = info
 
         def bwd():
+            if ctx.gs is not None:
+                ctx.gs.note(bn.gamma, y.gid); ctx.gs.note(bn.beta, y.gid)
             y.pre.coef()        # (a lazy output nobody consumed in the forward pass: finalize now)
             if info["fused"] and APPLY_FIN and x.needs_grad:
                 # the sums were produced by the consumer's backward kernel: finalize + apply in one launch
-                g, acc = ctx.grad_of(x)
+                g, acc = ctx.grad_of(x, y.gid)
                 call("nvae_bn_bwd_apply_fin", ctx.dt, ptr(xt), ptr(y.g), ptr(g), rows, Cc, ptr(info["partials"]),
                      info["mtiles"], scale, shift, mean, invstd, dgamma, dbeta, act, frozen, acc)
                 return
@@ -637,7 +764,7 @@ def bn_act(ctx: Ctx, x: Var, bn, act: int = L.ACT_NONE, lazy: bool = True) -> Va
                 call("nvae_bn_bwd_finalize_s", ctx.dt, ptr(info["partials"]), info["mtiles"], rows, Cc, scale, mean, invstd,
                      dgamma, dbeta, ptr(info["k0k1"]), frozen)
                 if x.needs_grad:
-                    g, acc = ctx.grad_of(x)
+                    g, acc = ctx.grad_of(x, y.gid)
                     call("nvae_bn_bwd_apply", ctx.dt, ptr(xt), ptr(y.g), ptr(g), rows, Cc, scale, shift,
                          ptr(info["k0k1"]), act, acc)
                 return
@@ -645,7 +772,7 @@ def bn_act(ctx: Ctx, x: Var, bn, act: int = L.ACT_NONE, lazy: bool = True) -> Va
             if BN_BWD_SPLIT and APPLY_FIN and x.needs_grad:
                 # plain strip reduce (no last-arriver hand-off) + the apply pass that finishes the slab itself
                 call("nvae_bn_bwd_reduce", ctx.dt, ptr(xt), ptr(y.g), rows, Cc, scale, shift, act, ptr(part))
-                g, acc = ctx.grad_of(x)
+                g, acc = ctx.grad_of(x, y.gid)
                 call("nvae_bn_bwd_apply_fin", ctx.dt, ptr(xt), ptr(y.g), ptr(g), rows, Cc, ptr(part), S, scale, shift,
                      mean, invstd, dgamma, dbeta, act, frozen, acc)
                 return
@@ -658,7 +785,7 @@ def bn_act(ctx: Ctx, x: Var, bn, act: int = L.ACT_NONE, lazy: bool = True) -> Va
                 call("nvae_bn_bwd_finalize", ctx.dt, ptr(part), rows, Cc, scale, mean, invstd, dgamma, dbeta, ptr(k0k1),
                      frozen)
             if x.needs_grad:
-                g, acc = ctx.grad_of(x)
+                g, acc = ctx.grad_of(x, y.gid)
                 call("nvae_bn_bwd_apply", ctx.dt, ptr(xt), ptr(y.g), ptr(g), rows, Cc, scale, shift,
                      ptr(k0k1), act, acc)
             _ = coef   # keep alive
@@ -727,14 +854,17 @@ def se_residual(ctx: Ctx, x: Var, se, skip: Var, skip_scale: float, branch_scale
                  branch_scale)
     if ctx.record:
         def bwd():
+            if ctx.gs is not None:
+                for sl in (se.w1, se.b1, se.w2, se.b2):
+                    ctx.gs.note(sl, y.gid)
             scratch = ctx.empty((B, Cc + Hd), torch.float32)
             gp = ptr(ps.grads)
             src = x.bn_src
             fuse = FUSE_BN_BWD and src is not None and x.uses == 1 and x.g is None
             if fused:
-                gx, accx = ctx.grad_of(x)
+                gx, accx = ctx.grad_of(x, y.gid)
                 if skip.needs_grad:
-                    gs, accs = ctx.grad_of(skip)
+                    gs, accs = ctx.grad_of(skip, y.gid)
                     gs_ptr = ptr(gs)
                 else:
                     gs_ptr, accs = None, 0
@@ -773,9 +903,9 @@ def se_residual(ctx: Ctx, x: Var, se, skip: Var, skip_scale: float, branch_scale
             # the FC parameter gradients are off the data-gradient chain: side stream, like the conv wgrads
             ctx.defer_se_wgrad((B, HW, Cc, Hd), pooled, hidden, scratch,
                                (gp + se.w1.off * 4, gp + se.b1.off * 4, gp + se.w2.off * 4, gp + se.b2.off * 4))
-            gx, accx = ctx.grad_of(x)
+            gx, accx = ctx.grad_of(x, y.gid)
             if skip.needs_grad:
-                gs, accs = ctx.grad_of(skip)
+                gs, accs = ctx.grad_of(skip, y.gid)
                 gs_ptr = ptr(gs)
             else:
                 gs_ptr, accs = None, 0
@@ -817,10 +947,16 @@ def sampler(ctx: Ctx, enc_p: Var, dec_p: Optional[Var], eps: torch.Tensor, kl_ou
     if ctx.record:
         def bwd():
             enc_p.g = ctx.empty(enc_p.t.shape)
+            enc_p.gid = z.gid
             d_dec = None
             if dec_p is not None:
                 dec_p.g = ctx.empty(dec_p.t.shape)
+                dec_p.gid = z.gid
                 d_dec = ptr(dec_p.g)
+            if ctx.gs is not None:      # the KL seed joins dz on dz's exponent
+                call("nvae_sampler_bwd_scaled", ctx.dt, ptr(enc_p.t), dp, ptr(eps), ptr(z.g), ptr(coeff), ptr(hyper),
+                     inv_batch, ptr(enc_p.g), d_dec, B, H * W, Lc, ptr(ctx.gs.scales), z.gid)
+                return
             call("nvae_sampler_bwd", ctx.dt, ptr(enc_p.t), dp, ptr(eps), ptr(z.g), ptr(coeff), ptr(hyper),
                  inv_batch, ptr(enc_p.g), d_dec, B, H * W, Lc)
         ctx.tape.append(bwd)

@@ -85,6 +85,6 @@ class Postprocess:
 
     def __call__(self, ctx: Ctx, x: Var) -> Var:
         for cell in self.cells:
-            x = cell(ctx, x)
+            x = cell(ctx, ops.grad_boundary(ctx, x))
         x = ops.unary(ctx, x, L.OP_ELU)                              # postprocess.py:27
         return ops.conv2d(ctx, x, self.final_conv, out_f32=True)     # logits stay f32

@@ -84,5 +84,5 @@ class Preprocess:
         x = ops.affine(ctx, inputs, 2.0, -1.0)   # [0,1] -> [-1,1], preprocess.py:38-39
         x = ops.conv2d(ctx, x, self.stem)
         for cell in self.cells:
-            x = cell(ctx, x)
+            x = cell(ctx, ops.grad_boundary(ctx, x))
         return x

@@ -122,17 +122,17 @@ def test_train_step_parity(lib, dev, dtype, ltol, gtol):
         assert not bad, bad[:10]
     else:
         # bf16.  Round 2 exempted a blanket 2 % of the tensors after one run in four showed post.cell0.se.b1 / se.w1 /
-        # bn3.beta at 0.4-1.0 of their scale.  Now every tensor has its own bound: max(gtol, 3 x the spread a correct
+        # bn3.beta at 0.4-1.0 of their scale.  Now every tensor has its own bound: max(gtol, 2 x the spread a correct
         # bf16 implementation has at THIS input, measured on the oracle itself: bf16_spread above).  The tensors that get
-        # a widened bound are listed; they are the ones the emulation itself moves by more than gtol / 3 (profiles/
+        # a widened bound are listed; they are the ones the emulation itself moves by more than gtol / 2 (profiles/
         # r03_bf16_spread.txt: SE parameters of cells where a hidden unit sits at its ReLU kink, and the BatchNorm in
         # front of that SE).  Everything else - and the distribution as a whole - keeps the tight bound.
         orc.steps = 100
         spread = bf16_spread(orc, snap, x, eps, out_o["grads"])
-        widened = sorted(((v, k) for k, v in spread.items() if 3 * v > gtol), reverse=True)
-        print("tensors whose own bf16 spread exceeds gtol / 3 (bound widened to 3 x spread):", widened[:12])
-        assert len(widened) <= max(4, len(valid) // 25), widened
-        over = [(e, k, spread[k]) for e, k in bad if e > max(gtol, 3 * spread[k])]
+        widened = sorted(((v, k) for k, v in spread.items() if 2 * v > gtol), reverse=True)
+        print("tensors whose own bf16 spread exceeds gtol / 2 (bound widened to 2 x spread):", widened[:12])
+        assert len(widened) <= 8, widened        # measured: 5 (post.cell0.se.b1 / se.w1 / bn3.beta, pre.cell0.se.w1 / se.b1)
+        over = [(e, k, spread[k]) for e, k in bad if e > max(gtol, 2 * spread[k])]
         assert not over, over[:10]
         assert valid[len(valid) // 2] < 5e-2 and valid[len(valid) * 9 // 10] < 9e-2
     # direction of the whole gradient
@@ -492,3 +492,27 @@ def test_c2_architecture_parity_bf16(lib, dev):
     assert kl_h < max(6e-2, 3 * kl_e)
     assert 1 - cos_h < max(2e-2, 3 * (1 - cos_e))
     assert med_h < max(8e-2, 2 * med_e) and p90_h < max(0.2, 2 * p90_e)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["f16", "bf16"])
+def test_grad_range_normalisation_is_transparent(lib, dev, dtype):
+    """The device-side renormalisation of the activation gradients (ops.GradScale: float16 on deep hierarchies) multiplies
+    by powers of two and divides them out of the f32 parameter gradients again: where nothing over- or underflows the
+    training step with it must equal the step without it up to the roundings of the merges - every parameter gradient
+    of the shrunken parity model, losses, and the Adamax update."""
+    _, m_off, x, eps = build_pair(dev, dtype)
+    _, m_on, _, _ = build_pair(dev, dtype)
+    m_on.grad_rescale, m_off.grad_rescale = True, False
+    outs = []
+    for m in (m_off, m_on):
+        m.steps = 100
+        outs.append(m.train_step(x.float(), [e.float() for e in eps]))
+    torch.cuda.synchronize()
+    assert abs(float(outs[0]["loss"]) - float(outs[1]["loss"])) < 1e-3 * abs(float(outs[0]["loss"]))
+    worst = sorted(((rel(m_on.ps.get_grad(k), m_off.ps.get_grad(k)), k) for k in m_on.ps.slots
+                    if float(m_off.ps.get_grad(k).abs().max()) > 0), reverse=True)
+    print("largest differences with / without range normalisation:", worst[:5])
+    # (the two runs also differ by the order of their f32 atomics, like any two runs)
+    assert worst[0][0] < (2e-2 if dtype == torch.float16 else 0.15), worst[:5]
+    assert worst[len(worst) // 2][0] < (2e-3 if dtype == torch.float16 else 2e-2)
+    assert rel(m_on.ps.params, m_off.ps.params) < 1e-4

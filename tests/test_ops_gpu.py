@@ -895,3 +895,38 @@ def test_bad_arguments_fail_loudly(lib, dev):
     g = L.ConvGeom(1, 4, 4, 3, 4, 4, 8, 3, 3, 1, 1, 1, 1, 0, 3, 8, 8)
     with pytest.raises(RuntimeError, match="conv_direct"):
         L.call("nvae_conv_gemm", L.BF16, C.byref(g), L.ptr(x), L.ptr(x), 32, None, None, L.ptr(x), 0, None)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
+def test_grad_range_normalisation_kernels(lib, dev, dtype):
+    """nvae_grad_amax / _rescale / _merge / _unscale (float16 on deep hierarchies): powers of two only, so every step is
+    exact and checked with torch.equal against the same arithmetic in torch."""
+    import math
+    n = 8192
+    g = torch.Generator().manual_seed(3)
+    a = (torch.randn(n, generator=g) * 3e-3).to(dev, dtype)
+    b = (torch.randn(n, generator=g) * 40.0).to(dev, dtype)
+    scales, amax = torch.zeros(8, device=dev), torch.zeros(8, device=dev)
+    dt = {torch.bfloat16: 1, torch.float16: 2}[dtype]
+    # a: tag 0 -> 1, b: tag 0 -> 2, both renormalised so that max |.| lands in (2^5, 2^6]
+    for t, idx in ((a, 1), (b, 2)):
+        ref, m = t.clone(), float(t.float().abs().max())
+        call("nvae_grad_amax", dt, ptr(t), n, ptr(amax) + 4 * idx)
+        assert float(amax[idx]) == m
+        call("nvae_grad_rescale", dt, ptr(t), n, ptr(amax) + 4 * idx, ptr(scales), 0, idx, 6.0)
+        k = math.floor(6.0 - math.log2(m))
+        assert float(scales[idx]) == k and 2.0 ** 5 < float(t.float().abs().max()) <= 2.0 ** 6
+        assert torch.equal(t, (ref.float() * 2.0 ** k).to(dtype))
+    # merge on the smaller exponent: the result carries min(k_a, k_b) under a fresh tag and cannot overflow
+    ka, kb = float(scales[1]), float(scales[2])
+    want = (a.float() * 2.0 ** (min(ka, kb) - ka) + b.float() * 2.0 ** (min(ka, kb) - kb)).to(dtype)
+    call("nvae_grad_merge", dt, ptr(a), ptr(b), n, ptr(scales), 1, 2, 3)
+    assert float(scales[3]) == min(ka, kb) and torch.equal(a, want) and bool(torch.isfinite(a).all())
+    # parameter gradients: ranges tagged 1 / 3 are divided by their factors, an untagged range is left alone
+    grads = torch.randn(64, generator=g).to(dev)
+    ref = grads.clone()
+    table = torch.tensor([0, 4, 1, 0, 6, 2, 3, 0], dtype=torch.int32, device=dev)       # floats [0,16) tag 1, [24,32) tag 3
+    call("nvae_grad_unscale", ptr(grads), ptr(table), 2, ptr(scales))
+    ref[0:16] *= 2.0 ** -ka
+    ref[24:32] *= 2.0 ** -min(ka, kb)
+    assert torch.equal(grads, ref)

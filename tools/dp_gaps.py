@@ -8,40 +8,24 @@ rows = []
 for r in csv.DictReader(open(f)):
     rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
 rows.sort()
-is_ccl = lambda n: "ccl" in n.lower()
+import re
+is_ccl = lambda n: re.search(r"nccl|rccl", n, re.I) is not None and "rocclr" not in n
 adamax = [i for i, r in enumerate(rows) if "k_adamax" in r[2]]
 print(f"{len(rows)} kernels, {len(adamax)} optimizer steps, {sum(is_ccl(r[2]) for r in rows)} RCCL kernels")
-# steps of the DP-configured model are the ones that contain RCCL kernels
+# per step (adamax end to adamax end): wall time, time with NO kernel running on any stream, kernels
 steps = []
 for a, b in zip(adamax[:-1], adamax[1:]):
-    n_ccl = sum(is_ccl(rows[i][2]) for i in range(a + 1, b + 1))
-    steps.append((a + 1, b, n_ccl, (rows[b][1] - rows[a][1]) / 1e3))
-plain = [s for s in steps if s[2] == 0]
-dp = [s for s in steps if s[2] > 0]
-med = lambda v: sorted(v)[len(v) // 2] if v else float("nan")
-print(f"step wall (adamax end to adamax end): plain median {med([s[3] for s in plain]):.1f} us over {len(plain)}, "
-      f"DP-configured median {med([s[3] for s in dp]):.1f} us over {len(dp)}")
-for kind, sel in (("plain", plain), ("DP", dp)):
-    if len(sel) < 3:
-        continue
-    lo, hi = sel[len(sel) // 2][:2]
-    busy_end = rows[lo][0]
-    idle, gaps = 0.0, []
-    for i in range(lo, hi + 1):
-        s, e, n = rows[i]
-        if s > busy_end:
-            idle += (s - busy_end) / 1e3
-            gaps.append(((s - busy_end) / 1e3, rows[i - 1][2][:50], n[:50]))
-        busy_end = max(busy_end, e)
-    gaps.sort(reverse=True)
-    print(f"--- {kind} step: {hi - lo + 1} kernels, chip completely idle for {idle:.1f} us in {len(gaps)} gaps; the largest:")
-    for g in gaps[:8]:
-        print(f"    {g[0]:7.1f} us   after {g[1]:50s} before {g[2]}")
-    if kind == "DP":
-        for i in range(lo, hi + 1):
-            if is_ccl(rows[i][2]):
-                s, e, n = rows[i]
-                prev_end = max(r[1] for r in rows[max(lo, i - 40):i]) if i > lo else s
-                nxt = rows[i + 1][0] if i + 1 <= hi else e
-                print(f"    RCCL {n[:40]:40s} dur {(e - s) / 1e3:7.1f} us, starts {(s - prev_end) / 1e3:7.1f} us after the last earlier "
-                      f"kernel ended, next kernel starts {(nxt - e) / 1e3:7.1f} us after it ends")
+    busy_end, idle, gaps = rows[a][1], 0.0, []
+    for i in range(a + 1, b + 1):
+        s_, e_, n_ = rows[i]
+        if s_ > busy_end:
+            idle += (s_ - busy_end) / 1e3
+            gaps.append(((s_ - busy_end) / 1e3, rows[i - 1][2][:48], n_[:48]))
+        busy_end = max(busy_end, e_)
+    steps.append(((rows[b][1] - rows[a][1]) / 1e3, idle, b - a, sum(is_ccl(rows[i][2]) for i in range(a + 1, b + 1)), sorted(gaps, reverse=True)[:6]))
+for i, (wall, idle, n, nccl, gaps) in enumerate(steps):
+    print(f"step {i:2d}: wall {wall:9.1f} us  chip idle {idle:8.1f} us  kernels {n:5d}  rccl kernels {nccl}")
+for i in (len(steps) // 4, 3 * len(steps) // 4):
+    print(f"--- largest idle gaps of step {i}:")
+    for g in steps[i][4]:
+        print(f"    {g[0]:7.1f} us   after {g[1]:48s} before {g[2]}")
