@@ -340,10 +340,22 @@ def time_dp_configured(args, device, dtype, x, plain_step):
             dist.all_reduce(torch.zeros(1, device=device)); torch.cuda.synchronize()
     try:
         m = make_model(device, dtype, args.batch)
-        m.reducer = parallel.GradReducer(force=True)
+        m.reducer = parallel.GradReducer(force=True, bucket_bytes=int(os.environ.get("NVAE_DP_BUCKET_MB", "64")) << 20)
         m.capture_train_step(x.shape, warmup=1)
         m._static_x.copy_(x.to(dtype))
         dp_step = lambda: m.train_step_graphed(None)
+        # host time inside the reducer's calls (a collective that blocks the host shows up here)
+        host = {"calls": 0, "s": 0.0}
+        for name in ("allreduce_mean_", "start_allreduce_", "finish_allreduce_", "allreduce_grads_"):
+            def wrap(fn):
+                def timed_call(*a, **k):
+                    t0 = time.perf_counter()
+                    r = fn(*a, **k)
+                    host["s"] += time.perf_counter() - t0
+                    host["calls"] += 1
+                    return r
+                return timed_call
+            setattr(m.reducer, name, wrap(getattr(m.reducer, name)))
 
         def timed(fn, n):
             torch.cuda.synchronize()
@@ -356,14 +368,17 @@ def time_dp_configured(args, device, dtype, x, plain_step):
             dp_step()
         rounds, n = 5, max(args.steps // 2, 4)
         plain, dp = [], []
+        host["calls"], host["s"] = 0, 0.0
         for _ in range(rounds):
             plain.append(timed(plain_step, n)[0])
             t, out = timed(dp_step, n)
             dp.append(t)
+        host_ms = host["s"] / (rounds * n) * 1e3
         med = lambda v: sorted(v)[len(v) // 2]
         segs = [m.grad_range(k) for k in range(m.n_segments())] if m._dp_segments() else [(0, int(m.ps.grads.numel()))]
         return {"ms_per_step": med(dp), "plain_ms_per_step": med(plain), "dp_overhead_ms": med(dp) - med(plain),
                 "ratio": med(dp) / med(plain), "rounds_ms": {"plain": [round(v, 3) for v in plain], "dp": [round(v, 3) for v in dp]},
+                "host_ms_inside_reducer_calls_per_step": round(host_ms, 3), "reducer_calls_per_step": host["calls"] / (rounds * n),
                 "backward_segments": len(segs),
                 "segment_gradient_mbytes": [round((hi - lo) * 4 / 1e6, 1) for lo, hi in segs],
                 "allreduce_bytes_per_step": int(m.ps.grads.numel()) * 4, "loss_nats": float(out["loss"]),

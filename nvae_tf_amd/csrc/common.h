@@ -130,7 +130,10 @@ template <> __device__ __forceinline__ void stf<f16>(f16* p, float v) { *p = (f1
 // ---------------------------------------------------------------------------------------
 // math
 // ---------------------------------------------------------------------------------------
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+// v_rcp_f32 (1 ulp) instead of an IEEE division: hipcc expands `1.0f / d` into 11 VALU instructions (two v_div_scale, v_rcp,
+// four v_fma, v_mul, v_div_fmas, v_div_fixup), which made every Swish 14 instructions instead of 4 - measurable where
+// the activation is applied redundantly (conv operand prologue, depthwise LDS prologue, BatchNorm-backward epilogue)
+__device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 __device__ __forceinline__ float swishf_(float x) { return x * sigmoidf_(x); }
 __device__ __forceinline__ float dswishf_(float x) {
     float s = sigmoidf_(x);

@@ -464,14 +464,15 @@ __global__ __launch_bounds__(WM* WN * 64) void k_conv_gemm2(
 
     // prologue state: the (tap, channel) position of ring step t, which lags `issue` by STAGES-1 steps
     int p_kh = kh, p_kw = kw, p_ci = ci, p_kabs = kabs;
-    if constexpr (PRE) {
-        for (int c = tid; c < g.Cin; c += NT) bn_coef<sizeof(T) == 4>(pre.bn, g.Cin, c, blockIdx.x == 0, pre_tab[c], pre_tab[PRE_MAXC + c]);
-        __syncthreads();
-    }
     const int nk_all = (K + BKE - 1) / BKE;
     const int nk = nk_all - t_begin < sk.steps ? nk_all - t_begin : sk.steps;
     const int fr = lane & 15, fq = lane >> 4;
     issue(0);
+    if constexpr (PRE) {
+        // (behind the first stage's DMA: the slab -> coefficient chain is a dependent global round trip + f64 arithmetic)
+        for (int c = tid; c < g.Cin; c += NT) bn_coef<sizeof(T) == 4>(pre.bn, g.Cin, c, blockIdx.x == 0, pre_tab[c], pre_tab[PRE_MAXC + c]);
+        __syncthreads();
+    }
 #pragma unroll
     for (int q = 1; q < STAGES - 1; ++q)
         if (nk > q) issue(q);
@@ -982,11 +983,7 @@ __global__ __launch_bounds__(512) void k_conv_img(
                               : (const void*)zeros;
         glds16(p, b_base + (unsigned)(cc * B_CC + B_MAIN + (wave & 1) * 64) * 16u);
     }
-    if constexpr (PRE) {
-        for (int c = tid; c < CIN; c += NT) bn_coef<false>(pre.bn, CIN, c, blockIdx.x == 0, pre_tab[c], pre_tab[CIN + c]);
-    }
-#pragma unroll
-    for (int cc = 0; cc < NCC; ++cc) {
+    auto issue_cc = [&](int cc) {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
             glds16(a_ok[i] ? (const void*)(a_src[i] + cc * 64) : (const void*)zeros,
@@ -995,7 +992,15 @@ __global__ __launch_bounds__(512) void k_conv_img(
         for (int i = 0; i < 2; ++i)
             glds16(b_ok[i] ? (const void*)(b_src[i] + cc * 64) : (const void*)zeros,
                    b_base + (unsigned)(cc * B_CC + 512 * i + wave * 64) * 16u);
+    };
+    issue_cc(0);
+    if constexpr (PRE) {
+        // the slab -> coefficient chain (a dependent global round trip + f64 arithmetic) runs behind chunk 0's DMA; hipcc
+        // waits vmcnt(0) for these loads, i.e. for chunk 0 as well, which is needed first anyway
+        for (int c = tid; c < CIN; c += NT) bn_coef<false>(pre.bn, CIN, c, blockIdx.x == 0, pre_tab[c], pre_tab[CIN + c]);
     }
+#pragma unroll
+    for (int cc = 1; cc < NCC; ++cc) issue_cc(cc);
 
     // ---- per-lane tap geometry: this lane's output pixel and which of the 9 source pixels exist
     const int fr = lane & 15, fq = lane >> 4;

@@ -37,8 +37,11 @@ OVERLAP_ADAMAX = os.environ.get("NVAE_OVERLAP_ADAMAX", "0") != "0"
 # data parallel: backward segments (each its own hipGraph, its gradient range all-reduced while the next one runs):
 # 5 = postprocess | decoder | three encoder + preprocess pieces, 4 / 3 = fewer encoder cuts, 2 = postprocess + decoder |
 # encoder + preprocess, 1 = one backward graph and one all-reduce behind it (no overlap)
-DP_SEGMENTS = int(os.environ.get("NVAE_DP_SEGMENTS", "5"))
+DP_SEGMENTS = int(os.environ.get("NVAE_DP_SEGMENTS", "4"))
 DP_DW_PRE = os.environ.get("NVAE_DP_DW_PRE", "0") != "0"      # keep the depthwise BN prologue when data parallel
+# single-GPU diagnostics of the data-parallel step's overhead (tools: bench.py --force-dp): leave out one of its collectives
+DP_DIAG_SKIP_AM = os.environ.get("NVAE_DP_DIAG_SKIP_AM", "0") != "0"
+DP_DIAG_SKIP_GRADS = os.environ.get("NVAE_DP_DIAG_SKIP_GRADS", "0") != "0"
 
 
 class NVAE:
@@ -410,7 +413,7 @@ class NVAE:
     def n_segments(self) -> int:
         return len(self._segments)
 
-    def _seg_backward(self, ctx: Ctx, B: int, part: Optional[int] = None, join: bool = True):
+    def _seg_backward(self, ctx: Ctx, B: int, part: Optional[int] = None, join: bool = True, flush: bool = True):
         """Loss + backward.  part=None: everything.  part k: segment k of `self._segments` (postprocess, decoder,
         then the encoder + preprocess pieces; run in that order); after part k the gradients of flat-buffer
         range `self.grad_range(k)` are final."""
@@ -429,8 +432,13 @@ class NVAE:
             glo, ghi = 0, ps.grads.numel()
         else:
             lo, hi = self._segments[part][:2]
-            ctx.backward(lo, hi if part else None, join=join)      # (the loss ops appended after the forward pass belong to segment 0)
+            ctx.backward(lo, hi if part else None, join=join, flush=flush)      # (the loss ops appended after the forward pass belong to segment 0)
             glo, ghi = self.grad_range(part)
+        if flush:
+            self._seg_finish_grads(ctx, glo, ghi, join)
+
+    def _seg_finish_grads(self, ctx: Ctx, glo: int, ghi: int, join: bool):
+        ps = self.ps
         if ctx.gs is not None:
             # range-normalised backward pass: the parameter gradients of this range carry their dy's power-of-two tag until
             # here; the regulariser's subgradient (true scale) is added afterwards, for the layers of this range
@@ -615,17 +623,18 @@ class NVAE:
             self._static_x.copy_(self._as_input(data))
         self._set_hyper()
         g1.replay()
-        if self.reducer is not None:
+        if self.reducer is not None and not DP_DIAG_SKIP_AM:
             self.reducer.allreduce_mean_(self.am)
         if isinstance(g2, list):
             works = []
             for part, g in enumerate(g2):
                 g.replay()
-                self.reducer.start_allreduce_(self.ps.grads, *self.grad_range(part), works)
+                if not DP_DIAG_SKIP_GRADS:
+                    self.reducer.start_allreduce_(self.ps.grads, *self.grad_range(part), works)
             self.reducer.finish_allreduce_(works)
         else:
             g2.replay()
-            if self.reducer is not None:
+            if self.reducer is not None and not DP_DIAG_SKIP_GRADS:
                 self.reducer.allreduce_grads_(self.ps.grads)
         if g3 is not None:
             g3.replay()

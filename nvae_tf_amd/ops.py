@@ -77,7 +77,7 @@ DW_PRE = os.environ.get("NVAE_DW_PRE", "1") != "0"           # BN(+Swish) in fro
 BN_BWD_SPLIT = os.environ.get("NVAE_BN_BWD_SPLIT", "0") != "0"  # unfused BN backward: reduce + self-finishing apply
 
 
-GRAD_TARGET_LOG2 = float(os.environ.get("NVAE_GRAD_TARGET_LOG2", "6"))   # renormalised activation gradients peak at 2^6
+GRAD_TARGET_LOG2 = float(os.environ.get("NVAE_GRAD_TARGET_LOG2", "-4"))   # renormalised activation gradients peak at 2^-4 (see GradScale)
 
 
 class GradScale:
@@ -332,13 +332,19 @@ class Ctx:
                 fn()
         self.deferred.clear()
 
-    def backward(self, lo: int = 0, hi: Optional[int] = None, join: bool = True):
+    def backward(self, lo: int = 0, hi: Optional[int] = None, join: bool = True, flush: bool = True,
+                 pre_flush: bool = False):
         """Run the tape entries [lo, hi) in reverse and join the side stream, so that every gradient
         those entries produce is complete on the current stream.  backward() runs the whole tape;
         data-parallel steps run it in segments and all-reduce each segment's parameters meanwhile.
         join=False leaves the queued side-stream work forked (the caller continues on the side stream with
-        `fork` and joins once at the end with `join_side`)."""
+        `fork` and joins once at the end with `join_side`).  flush=False does not even launch it: the weight-gradient
+        work of the range stays queued for `flush_inline` (data parallel: it becomes a graph / a side-stream batch of
+        its own, so that the main chain never waits for it between segments).  pre_flush=True first forks what earlier
+        calls left queued (data parallel: the PREVIOUS segment's weight gradients run under this segment's main chain)."""
         hi = len(self.tape) if hi is None else hi
+        if pre_flush:
+            self.flush_side()
         if self.gs is None:
             for fn in reversed(self.tape[lo:hi]):
                 fn()
@@ -346,12 +352,21 @@ class Ctx:
             for fn in reversed(self.tape[lo:hi]):
                 fn()
                 self.gs.flush()
-        self.flush_side()
+        if flush:
+            self.flush_side()
         if join:
             self.join_side()
         del self.tape[lo:hi]
-        if not self.tape and join:
+        if not self.tape and join and flush:
             self.keep.clear()
+
+    def flush_inline(self):
+        """Launch everything queued for the side stream on the CURRENT stream (the caller has switched to the side stream,
+        or is capturing this batch as a graph of its own)."""
+        self._launch_wgrads()
+        for fn in self.deferred:
+            fn()
+        self.deferred.clear()
 
     def fork(self, fn: Callable[[], None]):
         """Run fn on the side stream after everything issued so far on either stream."""

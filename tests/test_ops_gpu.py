@@ -902,6 +902,7 @@ def test_grad_range_normalisation_kernels(lib, dev, dtype):
     """nvae_grad_amax / _rescale / _merge / _unscale (float16 on deep hierarchies): powers of two only, so every step is
     exact and checked with torch.equal against the same arithmetic in torch."""
     import math
+    from nvae_tf_amd._lib import call, ptr
     n = 8192
     g = torch.Generator().manual_seed(3)
     a = (torch.randn(n, generator=g) * 3e-3).to(dev, dtype)

@@ -19,6 +19,8 @@ if x is None:
 
 def run(dtype, scale):
     m = configs.build(name, device=dev, dtype=dtype, loss_scale=scale)
+    m.steps = 2000          # beta = 0.04, as the full-batch test (training really begins in the KL warm-up)
+    print(f"{dtype}: gradient range normalisation {'on' if m.grad_rescale else 'off'}", flush=True)
     ge = torch.Generator().manual_seed(11)
     eps = [torch.randn(s, generator=ge) for s in m.eps_shapes(B)]
     m.train_step(x, eps_list=eps, update=False)
@@ -41,6 +43,9 @@ for k in f16:
     fin = t[torch.isfinite(t)]
     a[2] = max(a[2], float(fin.abs().max()) if fin.numel() else 0.0)
     a[3] = max(a[3], float(ref[k].abs().max()))
+bad = [k for k, a in agg.items() if a[1]]
+print(f"SUMMARY target 2^{os.environ.get('NVAE_GRAD_TARGET_LOG2', '6')} loss scale 2^{e}: {len(bad)} of {len(agg)} prefixes hold a "
+      f"non-finite gradient; first (in forward order) {bad[0] if bad else None}, last {bad[-1] if bad else None}", flush=True)
 print(f"{name}, f16 loss scale 2^{e}: prefix  tensors  non-finite  max finite |g| (f16)  max |g| (bf16)")
 for k, a in agg.items():
     print(f"  {k:22s} {a[0]:4d} {a[1]:4d}   {a[2]:10.3e}   {a[3]:10.3e}")
