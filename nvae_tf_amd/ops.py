@@ -62,11 +62,13 @@ FUSED_FIN = os.environ.get("NVAE_BN_FUSED_FIN", "1") != "0"
 APPLY_FIN = os.environ.get("NVAE_BN_APPLY_FIN", "1") != "0"   # slab -> coefficients inside the apply kernels
 SE_STATS = os.environ.get("NVAE_SE_STATS", "1") != "0"         # BN statistics out of the SE + residual kernel
 SE_FUSED = os.environ.get("NVAE_SE_FUSED", "1") != "0"         # SE + residual (+ the BatchNorm in front) as one launch
-# BatchNorm(+Swish) applied in the consuming conv's operand prologue (nvae_conv_gemm_ex): "0" never, "1" where it
-# measured faster than the separate apply pass (1x1 convs behind a BatchNorm WITHOUT activation: an im2col operand
-# is transformed once per tap and N-tile, which for Swish costs more VALU time than the pass it removes;
-# tools/bench_pre.py), "all" wherever the geometry allows (tests)
-CONV_PRE = os.environ.get("NVAE_CONV_PRE", "1")
+# BatchNorm(+Swish) applied in the consuming conv's operand prologue (nvae_conv_gemm_ex): "0" never; "1" 1x1 convs behind a
+# BatchNorm WITHOUT activation (+ the whole-image 3x3 kernel, CONV_PRE_IMG); "2" (default since round 3) 1x1 convs behind
+# any BatchNorm - an im2col operand is transformed once per N-tile (and per tap for k > 1), which for Swish used to cost more
+# VALU time than the apply pass it removes (tools/bench_pre.py); with the 4-instruction sigmoid of round 3 (common.h) the
+# 1x1 case pays: 19.42 / 19.40 -> 19.39 / 19.36 ms per step in two interleaved pairs, 34 launches fewer; "all" wherever the
+# geometry allows (tests)
+CONV_PRE = os.environ.get("NVAE_CONV_PRE", "2")
 # producers finalize the next BatchNorm in-kernel ("last arriver"): measured +5..12 us per conv launch against the
 # 4.8 us of a finalize launch or the ~0 of a consumer that reads the accumulated slab itself, so off by default
 CONV_PRE_IMG = os.environ.get("NVAE_CONV_PRE_IMG", "1") != "0"   # ... and 3x3 convs on the whole-image kernel (nvae_conv_img_ok)
@@ -488,8 +490,8 @@ def conv2d(ctx: Ctx, x: Var, conv, *, stride: int = 1, up: int = 1, pad: Optiona
     # operand prologue: x = act(BN(raw)) is applied inside the conv kernel (and, for the weight gradient, written
     # out once by it) when the gather is not upsampled and covers every source pixel as some output's centre tap
     lib = L.load()
-    pre_pays = CONV_PRE == "all" or (CONV_PRE == "1" and x.pre is not None and (
-        (k == 1 and x.pre.act == L.ACT_NONE) or
+    pre_pays = CONV_PRE == "all" or (CONV_PRE in ("1", "2") and x.pre is not None and (
+        (k == 1 and (x.pre.act == L.ACT_NONE or CONV_PRE == "2")) or
         # whole-image 3x3 kernel (4x4 / 8x8 towers): the tile is staged once, so the prologue costs 64 elements per thread
         (k == 3 and CONV_PRE_IMG and lib.nvae_conv_img_ok(ctx.dt, C.byref(g)) == 1)))
     use_pre = (pre_pays and fwd_mfma and x.pre is not None and x.pre.mat is None and up == 1 and cin == Cx and c_off == 0

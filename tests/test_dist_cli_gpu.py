@@ -47,6 +47,41 @@ def test_rccl_single_rank_graph_step(lib, dev):
         dist.destroy_process_group()
 
 
+def test_forced_dp_step_equals_plain_step_c2(lib, dev):
+    """The benchmarked model at the benchmarked size (C2, batch 128, bf16): the data-parallel step as ONE rank runs it -
+    segmented backward graphs, single-rank RCCL collectives on every bucket and on the KL statistic - is the plain
+    single-GPU step: same losses over three graph-replayed steps (the two runs differ by the order of their f32 atomics
+    and by the depthwise BatchNorm prologue that DP switches off: a bf16 rounding of one activation), parameters equal to
+    the Adamax-noise tolerance."""
+    import sys
+    import torch.distributed as dist
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from nvae_tf_amd.parallel import GradReducer
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(29400 + os.getpid() % 300)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        x = bench.synthetic_batch(128, 1, dev)
+        plain, dp = bench.make_model(dev, torch.bfloat16, 128), bench.make_model(dev, torch.bfloat16, 128)
+        dp.reducer = GradReducer(force=True)
+        assert torch.equal(plain.ps.params, dp.ps.params)
+        losses = []
+        for m in (plain, dp):
+            m.capture_train_step(x.shape, warmup=1)
+            m._static_x.copy_(x.to(torch.bfloat16))
+            losses.append([float(m.train_step_graphed(None)["loss"]) for _ in range(3)])
+        torch.cuda.synchronize()
+        assert dp.n_segments() >= 2 and isinstance(dp._plan[1], list)
+        print("plain / forced-DP losses:", losses)
+        for a, b in zip(*losses):
+            assert abs(a - b) / abs(a) < 2e-3, losses
+        d = (plain.ps.params - dp.ps.params).abs()
+        # three Adamax steps move an element by at most ~3 lr; elements whose gradient is noise may move in opposite directions
+        assert float(d.max()) < 6.5e-3 and float(torch.quantile(d[:: max(d.numel() // 1_000_000, 1)], 0.95)) < 1e-3
+    finally:
+        dist.destroy_process_group()
+
+
 def _dp_worker(rank, world, port, q):
     """One of two data-parallel ranks sharing the box's single GPU (gloo carries the collectives; the
     RCCL path needs one GPU per rank and is covered single-rank above and by the driver's N>1 runs)."""
