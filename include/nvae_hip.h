@@ -138,6 +138,9 @@ int nvae_conv_gemm_force_split(int S);
 int nvae_conv_img_ok(int dtype, const NvaeConvGeom* g);
 /* Tuning / test hook: 0 = never select the whole-image kernel (the generic implicit GEMM runs instead). */
 int nvae_conv_img_enable(int on);
+/* 16-bit dense 5x5 halo kernel: 1 = four waves of 128 x 96 with a software-pipelined loop, 0 = eight ping-pong waves of
+ * 64 x 96.  Results are bit-identical (same accumulation order per output element). */
+int nvae_conv_halo4_enable(int on);
 /* nvae_conv_gemm used as the DATA GRADIENT of a conv whose input was y = act(BN(x)) (the BNSwishConv /
  * ConvBNSwish pairs, encoder.py:91-98, decoder.py:125-135, postprocess.py:84-107): `out` receives dy
  * as usual and the epilogue additionally reduces dpre = dy * act'(scale*x + shift) against the same

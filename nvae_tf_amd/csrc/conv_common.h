@@ -22,6 +22,15 @@ __device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 acc) {
         return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc, 0, 0, 0);
 }
 
+// the same MFMA with the accumulator pinned in AGPRs, in place (hand-scheduled loops; no hazard bookkeeping by the
+// compiler: the caller keeps VALU reads of the accumulator >= 19 wait states behind the last of these)
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+template <typename T>
+__device__ __forceinline__ void mfma16_agpr(const i32x4& a, const i32x4& b, f32x4& acc) {
+    if constexpr (__is_same(T, bf16)) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+    else asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+}
+
 template <typename T>
 __device__ __forceinline__ void mfma_step(const uint4& a, const uint4& b, f32x4& acc) {
     if constexpr (sizeof(T) == 2) {

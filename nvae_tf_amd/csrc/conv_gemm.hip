@@ -753,154 +753,259 @@ __global__ __launch_bounds__(WM * 128) void k_conv_halo(
         for (int c = tid; c < g.Cin; c += NT) bn_coef<sizeof(T) == 4>(pre.bn, g.Cin, c, blockIdx.x == 0, pre_tab[c], pre_tab[PRE_MAXC_HALO + c]);
         __syncthreads();
     }
-#pragma unroll
-    for (int i = 0; i < A_PASSES; ++i) issue_a(0, 0, i);
-    issue_b(0, 0, 0);
-    int cc = 0, tap = 0;
-    // bf16, 8 waves: PING-PONG.  A SIMD hosts waves w and w + 4.  If all eight leave the per-step barrier together,
-    // both waves of a SIMD read LDS at the same time (matrix pipe idle) and then fight for the matrix pipe (each
-    // stalled half the time): measured 53-55 % MFMA-busy, 28 % of wave-cycles parked.  Here a step is
-    // [barrier R | 20 operand reads + this wave's share of the next DMA | barrier M | 48 MFMAs from registers] and
-    // waves 4-7 run ONE BARRIER behind waves 0-3 (they pass one extra barrier before the loop, waves 0-3 one after
-    // it): in every interval one wave of a SIMD issues MFMAs while the other reads.  Same code for both halves.
-    // Ring-slot lifetimes: B(s + 1) goes into the slot of B(s - 1), whose last reader (a lagging wave) finished
-    // before the leading waves' barrier R of step s, the first barrier after which anyone issues that DMA; every
-    // wave waits for its own DMA before EVERY barrier, so B(s + 1) is complete before the leading waves' barrier R
-    // of step s + 1 (the lagging waves' barrier M of step s).
+    constexpr bool PIPE4 = sizeof(T) == 2 && WM * WN == 4;
     constexpr bool PINGPONG = sizeof(T) == 2 && WM * WN == 8;
     const bool lag = PINGPONG && wave >= 4;
-    // prefetch(q): what step q's leading waves issue - the weight tile of step q + 1 and, during the first taps of a
-    // chunk, one pass of the next chunk's halo.  Leading waves call prefetch(s) in their read interval of step s
-    // (after barrier R of step s: the lagging waves finished reading that slot in the interval before).  Lagging
-    // waves call prefetch(s + 1) after THEIR barrier M of step s - the same point in time - so that their DMA
-    // also has a whole MFMA phase to land before their next loop-top wait (they are the last to pass a barrier
-    // before the leading waves read the tile).
-    auto prefetch = [&](int q, int tapq, int ccq) {
-        if (q >= S) return;
-        int ntap = tapq + 1, ncc_ = ccq;
-        if (ntap == TAPS) { ntap = 0; ++ncc_; }
-        if (q + 1 < S) issue_b((q + 1) & 1, ncc_, ntap);
-        if (tapq < A_PASSES && ccq + 1 < ncc) {
+    if constexpr (PIPE4) {
+        // 16-bit, FOUR waves of 128 x 96 (one per SIMD, accumulators 192 registers): 14 operand reads per 48 MFMAs instead
+        // of 20, and no second wave on the SIMD to hide them - so the loop is a hand-made software pipeline over HALF
+        // k-steps ("phases", 32 channels of one tap): while the 48 MFMAs of phase p run out of one register set, the 14
+        // ds_read_b128 of phase p + 1 are issued between them into the other (sched_group_barrier: one read per two
+        // MFMAs, all in flight after 28 MFMAs, 20 MFMAs of slack for the last one's latency).
+        // One barrier per STEP, at the end of its phase 0:
+        //   weight tile B(s) lives in ring slot s & 1 and is read in phase (s-1, 1) [first half] and (s, 0) [second
+        //   half]; B(s + 2) is DMA'd into the same slot in phase (s, 1), i.e. after the barrier of step s, which a wave
+        //   passes only with its reads of phase (s, 0) complete; every thread waits for its own pieces of B(s + 2)
+        //   before the barrier of step s + 1 (counted: at most the halo pass issued in that phase stays in flight), after
+        //   which phase (s + 1, 1) reads it.  Flight time of a weight piece: almost two phases, as in the 8-wave form.
+        //   Halo pass i of the next chunk is issued in phase (i, 0), is complete at the barrier of step i + 1 (where the
+        //   thread that issued it normalises it in place: ConvPre) and is read from phase (24, 1) on; the buffer it
+        //   lands in was last read in phase (24, 0) of the chunk before, one barrier earlier.
 #pragma unroll
-            for (int i = 0; i < A_PASSES; ++i)
-                if (i == tapq) issue_a((ccq + 1) & 1, ccq + 1, i);
-        }
-    };
-    if (lag) {
-        prefetch(0, 0, 0);
+        for (int i = 0; i < A_PASSES; ++i) issue_a(0, 0, i);
+        issue_b(0, 0, 0);
+        if (S > 1) issue_b(1, 0, 1);
         wait_vmcnt<0>();
         if constexpr (PRE) {
-            // the lagging waves' share of chunk 0's halo must be normalised BEFORE this barrier: it pairs with the
-            // leading waves' barrier R(0), after which they read the halo for tap 0
 #pragma unroll
             for (int i = 0; i < A_PASSES; ++i) pre_pass(0, i);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
         __builtin_amdgcn_s_barrier();
-    }
-    for (int s = 0; s < S; ++s) {
-        wait_vmcnt<0>();
-        if constexpr (PRE) {
-            if (s == 0) {
-                if (!lag) {
+        asm volatile("" ::: "memory");
+        const int lb = wm * MI * HP + fr;                           // halo row of this lane for (i = 0, tap 0)
+        const int bo0 = (wn * (BN / WN) + fr) * 8 + (fq ^ (fr & 7));          // weight rows are multiples of 8 apart
+        const int bo1 = (wn * (BN / WN) + fr) * 8 + ((4 + fq) ^ (fr & 7));
+        i32x4 af[2][MI], bf[2][NI];
+        // One phase: the 14 reads of the NEXT phase's fragments (6 weight, then 8 halo), each followed by two MFMAs of
+        // THIS phase, then the other 20 MFMAs.  The MFMAs are inline asm with the accumulators pinned in AGPRs ("+a"):
+        // as builtins the register allocator kept half of the 192 accumulator registers in VGPRs and moved every tile
+        // in and out of AGPRs around its MFMA (116 v_accvgpr_write per phase); sched_barrier keeps the source order.
+#define HALO4_PHASE(CUR, NXT, HN, ABUF, BBUF, TAPOFF)                                                              \
+        {                                                                                                          \
+            const i32x4* bb_ = (const i32x4*)(BBUF) + ((HN) ? bo1 : bo0);                                          \
+            const i32x4* ab_ = (const i32x4*)(ABUF);                                                               \
+            const int tb_ = lb + (TAPOFF);                                                                         \
+            _Pragma("unroll") for (int q = 0; q < MI + NI; ++q) {                                                  \
+                if (q < NI) bf[NXT][q < NI ? q : 0] = bb_[q * 128];                                                \
+                else {                                                                                             \
+                    const int hrow = tb_ + (q - NI) * HP;                                                          \
+                    af[NXT][q < NI ? 0 : q - NI] = ab_[hrow * 8 + (((HN) * 4 + fq) ^ (hrow & 7))];                 \
+                }                                                                                                  \
+                mfma16_agpr<T>(af[CUR][(2 * q) / NI], bf[CUR][(2 * q) % NI], acc[(2 * q) / NI][(2 * q) % NI]);      \
+                mfma16_agpr<T>(af[CUR][(2 * q + 1) / NI], bf[CUR][(2 * q + 1) % NI], acc[(2 * q + 1) / NI][(2 * q + 1) % NI]); \
+                __builtin_amdgcn_sched_barrier(0);                                                                 \
+            }                                                                                                      \
+            _Pragma("unroll") for (int k = 2 * (MI + NI); k < MI * NI; ++k)                                        \
+                mfma16_agpr<T>(af[CUR][k / NI], bf[CUR][k % NI], acc[k / NI][k % NI]);                             \
+            __builtin_amdgcn_sched_barrier(0);                                                                     \
+        }
+        {   // fragments of (step 0, first half)
+            const i32x4* bb_ = (const i32x4*)(lds + 2 * A_CHUNKS) + bo0;
 #pragma unroll
-                    for (int i = 0; i < A_PASSES; ++i) pre_pass(0, i);
-                }
-            } else if (tap >= 1 && tap <= A_PASSES && cc + 1 < ncc) {
-                // the pass issued one step ago (tap - 1) for the NEXT chunk has landed; its buffer is not read
-                // before chunk cc + 1 starts
+            for (int j = 0; j < NI; ++j) bf[0][j] = bb_[j * 128];
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                const int hrow = lb + i * HP;
+                af[0][i] = ((const i32x4*)lds)[hrow * 8 + (fq ^ (hrow & 7))];
+            }
+        }
+        int cc = 0, tap = 0, tap2 = 2 % TAPS, cc2 = 2 / TAPS;      // (tap2, cc2): two steps ahead
+        for (int s = 0; s < S; ++s) {
+            const int kh = tap / KS, kw = tap - kh * KS;
+            int tap1 = tap + 1, cc1 = cc;
+            if (tap1 == TAPS) { tap1 = 0; ++cc1; }
+            const int kh1 = tap1 / KS, kw1 = tap1 - kh1 * KS;
+            // ---- phase 0: MFMAs of (s, first half), reads of (s, second half), one halo pass of the next chunk
+            const bool a_pass = tap < A_PASSES && cc + 1 < ncc;
+            const bool a_mine = a_pass && NT * tap + wave * 64 < A_CHUNKS;
+            if (a_pass) {
 #pragma unroll
                 for (int i = 0; i < A_PASSES; ++i)
-                    if (i == tap - 1) pre_pass(cc + 1, i);
+                    if (i == tap) issue_a((cc + 1) & 1, cc + 1, i);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            HALO4_PHASE(0, 1, 1, lds + (cc & 1) * A_CHUNKS, lds + 2 * A_CHUNKS + (s & 1) * B_CHUNKS, kh * HP + kw)
+            if (a_mine) wait_vmcnt<1>(); else wait_vmcnt<0>();
+            if constexpr (PRE) {
+                if (tap >= 1 && tap <= A_PASSES && cc + 1 < ncc) {
+#pragma unroll
+                    for (int i = 0; i < A_PASSES; ++i)
+                        if (i == tap - 1) pre_pass(cc + 1, i);
+                }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        }
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        const uint4* abuf = lds + (cc & 1) * A_CHUNKS;
-        const uint4* bbuf = lds + 2 * A_CHUNKS + (s & 1) * B_CHUNKS;
-        const int kh = tap / KS, kw = tap - kh * KS;
-        int tap1 = tap + 1, cc1 = cc;
-        if (tap1 == TAPS) { tap1 = 0; ++cc1; }
-        if constexpr (PINGPONG) {
-            uint4 af[2][MI], bf[2][NI];
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-#pragma unroll
-                for (int i = 0; i < MI; ++i) {
-                    const int hrow = (wm * MI + i + kh) * HP + kw + fr;
-                    af[h][i] = abuf[hrow * 8 + ((h * 4 + fq) ^ (hrow & 7))];
-                }
-#pragma unroll
-                for (int j = 0; j < NI; ++j) {
-                    const int r = wn * (BN / WN) + j * 16 + fr;
-                    bf[h][j] = bbuf[r * 8 + ((h * 4 + fq) ^ (r & 7))];
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            if (!lag) prefetch(s, tap, cc);
-            __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            // ---- phase 1: MFMAs of (s, second half), reads of (s + 1, first half), DMA of the weight tile of step s + 2
+            if (s + 2 < S) issue_b(s & 1, cc2, tap2);
             __builtin_amdgcn_sched_barrier(0);
-            // (the lagging waves issue their DMA share at the head of their MFMA interval: it must be waited for one
-            // barrier earlier than the leading waves' share.  Spreading the DMA instructions between the MFMAs of
-            // both halves measured 223 us against 171: the fences and M0 writes break the MFMA stream.)
-            if (lag) prefetch(s + 1, tap1, cc1);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int h = 0; h < 2; ++h)
-#pragma unroll
-                for (int i = 0; i < MI; ++i)
-#pragma unroll
-                    for (int j = 0; j < NI; ++j) mfma_step<T>(af[h][i], bf[h][j], acc[i][j]);
-        } else if constexpr (sizeof(T) == 4) {
-            // f32: two-level accumulation, one partial per (tap, 32-channel chunk) -- see k_conv_gemm2
-            prefetch(s, tap, cc);
-            uint4 af[2][MI], bf[2][NI];
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-#pragma unroll
-                for (int i = 0; i < MI; ++i) {
-                    const int hrow = (wm * MI + i + kh) * HP + kw + fr;
-                    af[h][i] = abuf[hrow * 8 + ((h * 4 + fq) ^ (hrow & 7))];
-                }
-#pragma unroll
-                for (int j = 0; j < NI; ++j) {
-                    const int r = wn * (BN / WN) + j * 16 + fr;
-                    bf[h][j] = bbuf[r * 8 + ((h * 4 + fq) ^ (r & 7))];
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < MI; ++i)
-#pragma unroll
-                for (int j = 0; j < NI; ++j) {
-                    f32x4 part = (f32x4){0.f, 0.f, 0.f, 0.f};
-                    mfma_step<T>(af[0][i], bf[0][j], part);
-                    mfma_step<T>(af[1][i], bf[1][j], part);
-                    acc[i][j] += part;
-                }
-        } else {
-            prefetch(s, tap, cc);
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                uint4 af[MI], bf[NI];
-#pragma unroll
-                for (int i = 0; i < MI; ++i) {
-                    const int hrow = (wm * MI + i + kh) * HP + kw + fr;
-                    af[i] = abuf[hrow * 8 + ((h * 4 + fq) ^ (hrow & 7))];
-                }
-#pragma unroll
-                for (int j = 0; j < NI; ++j) {
-                    const int r = wn * (BN / WN) + j * 16 + fr;
-                    bf[j] = bbuf[r * 8 + ((h * 4 + fq) ^ (r & 7))];
-                }
-#pragma unroll
-                for (int i = 0; i < MI; ++i)
-#pragma unroll
-                    for (int j = 0; j < NI; ++j) mfma_step<T>(af[i], bf[j], acc[i][j]);
-            }
+            // (after the last step this reads a stale but valid tile; nothing uses it)
+            HALO4_PHASE(1, 0, 0, lds + (cc1 & 1) * A_CHUNKS, lds + 2 * A_CHUNKS + ((s + 1) & 1) * B_CHUNKS, kh1 * HP + kw1)
+            tap = tap1; cc = cc1;
+            if (++tap2 == TAPS) { tap2 = 0; ++cc2; }
         }
-        tap = tap1; cc = cc1;
+#undef HALO4_PHASE
+        // (the compiler does not know these were MFMAs: cover the XDL-write -> VALU-read distance by hand)
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+    } else {
+#pragma unroll
+        for (int i = 0; i < A_PASSES; ++i) issue_a(0, 0, i);
+        issue_b(0, 0, 0);
+        int cc = 0, tap = 0;
+        // bf16, 8 waves: PING-PONG.  A SIMD hosts waves w and w + 4.  If all eight leave the per-step barrier together,
+        // both waves of a SIMD read LDS at the same time (matrix pipe idle) and then fight for the matrix pipe (each
+        // stalled half the time): measured 53-55 % MFMA-busy, 28 % of wave-cycles parked.  Here a step is
+        // [barrier R | 20 operand reads + this wave's share of the next DMA | barrier M | 48 MFMAs from registers] and
+        // waves 4-7 run ONE BARRIER behind waves 0-3 (they pass one extra barrier before the loop, waves 0-3 one after
+        // it): in every interval one wave of a SIMD issues MFMAs while the other reads.  Same code for both halves.
+        // Ring-slot lifetimes: B(s + 1) goes into the slot of B(s - 1), whose last reader (a lagging wave) finished
+        // before the leading waves' barrier R of step s, the first barrier after which anyone issues that DMA; every
+        // wave waits for its own DMA before EVERY barrier, so B(s + 1) is complete before the leading waves' barrier R
+        // of step s + 1 (the lagging waves' barrier M of step s).
+        // prefetch(q): what step q's leading waves issue - the weight tile of step q + 1 and, during the first taps of a
+        // chunk, one pass of the next chunk's halo.  Leading waves call prefetch(s) in their read interval of step s
+        // (after barrier R of step s: the lagging waves finished reading that slot in the interval before).  Lagging
+        // waves call prefetch(s + 1) after THEIR barrier M of step s - the same point in time - so that their DMA
+        // also has a whole MFMA phase to land before their next loop-top wait (they are the last to pass a barrier
+        // before the leading waves read the tile).
+        auto prefetch = [&](int q, int tapq, int ccq) {
+            if (q >= S) return;
+            int ntap = tapq + 1, ncc_ = ccq;
+            if (ntap == TAPS) { ntap = 0; ++ncc_; }
+            if (q + 1 < S) issue_b((q + 1) & 1, ncc_, ntap);
+            if (tapq < A_PASSES && ccq + 1 < ncc) {
+#pragma unroll
+                for (int i = 0; i < A_PASSES; ++i)
+                    if (i == tapq) issue_a((ccq + 1) & 1, ccq + 1, i);
+            }
+        };
+        if (lag) {
+            prefetch(0, 0, 0);
+            wait_vmcnt<0>();
+            if constexpr (PRE) {
+                // the lagging waves' share of chunk 0's halo must be normalised BEFORE this barrier: it pairs with the
+                // leading waves' barrier R(0), after which they read the halo for tap 0
+#pragma unroll
+                for (int i = 0; i < A_PASSES; ++i) pre_pass(0, i);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_s_barrier();
+        }
+        for (int s = 0; s < S; ++s) {
+            wait_vmcnt<0>();
+            if constexpr (PRE) {
+                if (s == 0) {
+                    if (!lag) {
+#pragma unroll
+                        for (int i = 0; i < A_PASSES; ++i) pre_pass(0, i);
+                    }
+                } else if (tap >= 1 && tap <= A_PASSES && cc + 1 < ncc) {
+                    // the pass issued one step ago (tap - 1) for the NEXT chunk has landed; its buffer is not read
+                    // before chunk cc + 1 starts
+#pragma unroll
+                    for (int i = 0; i < A_PASSES; ++i)
+                        if (i == tap - 1) pre_pass(cc + 1, i);
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            const uint4* abuf = lds + (cc & 1) * A_CHUNKS;
+            const uint4* bbuf = lds + 2 * A_CHUNKS + (s & 1) * B_CHUNKS;
+            const int kh = tap / KS, kw = tap - kh * KS;
+            int tap1 = tap + 1, cc1 = cc;
+            if (tap1 == TAPS) { tap1 = 0; ++cc1; }
+            if constexpr (PINGPONG) {
+                uint4 af[2][MI], bf[2][NI];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+#pragma unroll
+                    for (int i = 0; i < MI; ++i) {
+                        const int hrow = (wm * MI + i + kh) * HP + kw + fr;
+                        af[h][i] = abuf[hrow * 8 + ((h * 4 + fq) ^ (hrow & 7))];
+                    }
+#pragma unroll
+                    for (int j = 0; j < NI; ++j) {
+                        const int r = wn * (BN / WN) + j * 16 + fr;
+                        bf[h][j] = bbuf[r * 8 + ((h * 4 + fq) ^ (r & 7))];
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (!lag) prefetch(s, tap, cc);
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                // (the lagging waves issue their DMA share at the head of their MFMA interval: it must be waited for one
+                // barrier earlier than the leading waves' share.  Spreading the DMA instructions between the MFMAs of
+                // both halves measured 223 us against 171: the fences and M0 writes break the MFMA stream.)
+                if (lag) prefetch(s + 1, tap1, cc1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int i = 0; i < MI; ++i)
+#pragma unroll
+                        for (int j = 0; j < NI; ++j) mfma_step<T>(af[h][i], bf[h][j], acc[i][j]);
+            } else if constexpr (sizeof(T) == 4) {
+                // f32: two-level accumulation, one partial per (tap, 32-channel chunk) -- see k_conv_gemm2
+                prefetch(s, tap, cc);
+                uint4 af[2][MI], bf[2][NI];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+#pragma unroll
+                    for (int i = 0; i < MI; ++i) {
+                        const int hrow = (wm * MI + i + kh) * HP + kw + fr;
+                        af[h][i] = abuf[hrow * 8 + ((h * 4 + fq) ^ (hrow & 7))];
+                    }
+#pragma unroll
+                    for (int j = 0; j < NI; ++j) {
+                        const int r = wn * (BN / WN) + j * 16 + fr;
+                        bf[h][j] = bbuf[r * 8 + ((h * 4 + fq) ^ (r & 7))];
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NI; ++j) {
+                        f32x4 part = (f32x4){0.f, 0.f, 0.f, 0.f};
+                        mfma_step<T>(af[0][i], bf[0][j], part);
+                        mfma_step<T>(af[1][i], bf[1][j], part);
+                        acc[i][j] += part;
+                    }
+            } else {
+                prefetch(s, tap, cc);
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    uint4 af[MI], bf[NI];
+#pragma unroll
+                    for (int i = 0; i < MI; ++i) {
+                        const int hrow = (wm * MI + i + kh) * HP + kw + fr;
+                        af[i] = abuf[hrow * 8 + ((h * 4 + fq) ^ (hrow & 7))];
+                    }
+#pragma unroll
+                    for (int j = 0; j < NI; ++j) {
+                        const int r = wn * (BN / WN) + j * 16 + fr;
+                        bf[j] = bbuf[r * 8 + ((h * 4 + fq) ^ (r & 7))];
+                    }
+#pragma unroll
+                    for (int i = 0; i < MI; ++i)
+#pragma unroll
+                        for (int j = 0; j < NI; ++j) mfma_step<T>(af[i], bf[j], acc[i][j]);
+                }
+            }
+            tap = tap1; cc = cc1;
+        }
     }
     if (PINGPONG && !lag) { wait_vmcnt<0>(); __builtin_amdgcn_s_barrier(); }
     int ticket = 0;
@@ -1062,6 +1167,9 @@ __global__ __launch_bounds__(512) void k_conv_img(
     }
 }
 
+// 5x5 halo kernel, 16-bit: four waves of 128 x 96 with a software-pipelined loop (1) or eight ping-pong waves of 64 x 96 (0)
+static bool g_halo4 = false;
+extern "C" int nvae_conv_halo4_enable(int on) { g_halo4 = on != 0; return NVAE_OK; }
 // whole-image kernel eligibility (must agree between the launcher and nvae_conv_gemm_stats_rows)
 static bool g_conv_img = true;
 extern "C" int nvae_conv_img_enable(int on) { g_conv_img = on != 0; return NVAE_OK; }
@@ -1205,6 +1313,12 @@ static int launch_conv_gemm(const NvaeConvGeom* g, const void* src, const void* 
         hipLaunchKernelGGL((k_conv_halo<T, 192, KS_, WM_, F_, P_>), mt * nt, WM_ * 128, 0, s, *g, (const T*)src, \
                            (const T*)wT, w_ld, bias, (const T*)residual, out, out_f32, nt, mt * nt, pw, ppi,  \
                            zeros, stats, vec_epi, be, pre, sfin);
+        if constexpr (sizeof(T) == 2) {
+            if (g->KH == 5 && g_halo4) {
+                if (be.x) LAUNCH_HALO(5, 2, true, false) else if (use_pre) LAUNCH_HALO(5, 2, false, true) else LAUNCH_HALO(5, 2, false, false)
+                return 0;
+            }
+        }
         if (g->KH == 5) { if (be.x) LAUNCH_HALO(5, HALO_WM, true, false) else if (use_pre) LAUNCH_HALO(5, HALO_WM, false, true) else LAUNCH_HALO(5, HALO_WM, false, false) }
         else { if (be.x) LAUNCH_HALO(3, 4, true, false) else if (use_pre) LAUNCH_HALO(3, 4, false, true) else LAUNCH_HALO(3, 4, false, false) }
 #undef LAUNCH_HALO

@@ -12,6 +12,13 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box with -m gpu)")
 
 
+def pytest_sessionstart(session):
+    # the GPU boxes show every core of the host but grant a 16-core share: without a cap the oracle's CPU convolutions run
+    # oversubscribed (measured: the fp64 C2 oracle step 7 s on 8 threads here, minutes there)
+    import torch
+    torch.set_num_threads(min(os.cpu_count() or 1, 16))
+
+
 @pytest.fixture(scope="session")
 def lib():
     """Build (if needed) and load libnvae_hip.so."""
