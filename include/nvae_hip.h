@@ -141,6 +141,11 @@ int nvae_conv_img_enable(int on);
 /* 16-bit dense 5x5 halo kernel: 1 = four waves of 128 x 96 with a software-pipelined loop, 0 = eight ping-pong waves of
  * 64 x 96.  Results are bit-identical (same accumulation order per output element). */
 int nvae_conv_halo4_enable(int on);
+/* Diagnostics of the halo kernel (tools/mb_halo.py).  nvae_conv_halo4_enable(form | 16): the kernel stamps s_memtime /
+ * s_memrealtime around its main loop and returns WITHOUT its epilogue; stamps = [tile][2] {d memtime, d memrealtime} (clock =
+ * ratio x 100 MHz).  nvae_conv_halo4_enable(form | 32): complete launches; stamps = [tile][4] absolute 100 MHz times at
+ * entry, loop start, loop end, exit.  This copies the first n values to the host (n <= 2048). */
+int nvae_conv_halo_stamps(unsigned long long* host_out, int n);
 /* nvae_conv_gemm used as the DATA GRADIENT of a conv whose input was y = act(BN(x)) (the BNSwishConv /
  * ConvBNSwish pairs, encoder.py:91-98, decoder.py:125-135, postprocess.py:84-107): `out` receives dy
  * as usual and the epilogue additionally reduces dpre = dy * act'(scale*x + shift) against the same

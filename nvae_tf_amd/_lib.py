@@ -72,6 +72,7 @@ _SIGS = {
     "nvae_conv_img_ok": None,
     "nvae_conv_img_enable": None,
     "nvae_conv_halo4_enable": None,
+    "nvae_conv_halo_stamps": None,
     "nvae_conv_gemm_bnbwd": [_i, _p, _p, _p, _i, _p, _p, _p, _p],
     "nvae_conv_wgrad_scratch": None,
     "nvae_conv_wgrad_scratch_n": None,
@@ -193,6 +194,8 @@ def load():
     lib.nvae_conv_img_enable.argtypes = [_i]
     lib.nvae_conv_halo4_enable.restype = C.c_int
     lib.nvae_conv_halo4_enable.argtypes = [_i]
+    lib.nvae_conv_halo_stamps.restype = C.c_int
+    lib.nvae_conv_halo_stamps.argtypes = [C.c_void_p, _i]
     lib.nvae_conv_gemm_pre_max_cin.restype = C.c_int
     lib.nvae_conv_gemm_pre_max_cin.argtypes = [_i, _G]
     lib.nvae_conv_wgrad_scratch.restype = C.c_long

@@ -652,6 +652,8 @@ __global__ __launch_bounds__(WM* WN * 64) void k_conv_gemm2(
 //   Halo rows are [pixel][8 chunks], slot = chunk ^ (row & 7): conflict-free for the 16x16x32 operand
 //   read at ANY row offset (the tap shift moves the 16-row window by kh*20 + kw rows).
 // =========================================================================================
+static __device__ unsigned long long g_halo_stamps[2048];     // diagnostic stamps, see nvae_conv_halo_stamps
+
 template <typename T, int BN, int KS, int WM, bool BNBWD, bool PRE>
 __global__ __launch_bounds__(WM * 128) void k_conv_halo(
     NvaeConvGeom g, const T* __restrict__ src, const T* __restrict__ wT, int w_ld,
@@ -754,8 +756,15 @@ __global__ __launch_bounds__(WM * 128) void k_conv_halo(
         __syncthreads();
     }
     constexpr bool PIPE4 = sizeof(T) == 2 && WM * WN == 4;
+    const int dbg = vec_epi >> 8;          // diagnostic stamps (nvae_conv_halo4_enable(form | 16 or 32)); 0 in production
+    vec_epi &= 0xff;
+    unsigned long long st_e = 0;
+    if (dbg & 16) st_e = __builtin_amdgcn_s_memrealtime();
     constexpr bool PINGPONG = sizeof(T) == 2 && WM * WN == 8;
     const bool lag = PINGPONG && wave >= 4;
+    // diagnostic stamps (DVFS give-back check of the microarchitecture guide: clock = d memtime / d memrealtime x 100 MHz)
+    unsigned long long st_c = 0, st_r = 0;
+    if (dbg & 24) { st_c = __builtin_amdgcn_s_memtime(); st_r = __builtin_amdgcn_s_memrealtime(); }
     if constexpr (PIPE4) {
         // 16-bit, FOUR waves of 128 x 96 (one per SIMD, accumulators 192 registers): 14 operand reads per 48 MFMAs instead
         // of 20, and no second wave on the SIMD to hide them - so the loop is a hand-made software pipeline over HALF
@@ -1008,6 +1017,13 @@ __global__ __launch_bounds__(WM * 128) void k_conv_halo(
         }
     }
     if (PINGPONG && !lag) { wait_vmcnt<0>(); __builtin_amdgcn_s_barrier(); }
+    if (dbg & 8) {
+        st_c = __builtin_amdgcn_s_memtime() - st_c; st_r = __builtin_amdgcn_s_memrealtime() - st_r;
+        if (tid == 0 && tile < 1024) { g_halo_stamps[2 * tile] = st_c; g_halo_stamps[2 * tile + 1] = st_r; }
+        return;
+    }
+    unsigned long long st_l = 0;
+    if (dbg & 16) st_l = __builtin_amdgcn_s_memrealtime();
     int ticket = 0;
     conv_epilogue<T, BM, BN, WM, WN, BNBWD>(acc, (float*)lds, g, bias, residual, out, out_f32, bp, bn, stats, vec_epi,
                                             [&](int r) -> long { return ((long)b * H + py0 + (r >> 4)) * W + px0 + (r & 15); }, be,
@@ -1015,6 +1031,14 @@ __global__ __launch_bounds__(WM * 128) void k_conv_halo(
     if constexpr (!BNBWD) {
         if (stats && sfin.counter && bn_was_last(sfin.counter + bn, ticket, be.m_tiles))
             bn_fin_fwd<sizeof(T) == 4>(sfin, stats, be.rows, N, bn * BN, (BN + 63) / 64);
+    }
+    if (dbg & 16) {
+        // absolute 100 MHz stamps: entry, loop start, loop end, exit (stores issued, not necessarily landed)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (tid == 0 && tile < 512) {
+            g_halo_stamps[4 * tile] = st_e; g_halo_stamps[4 * tile + 1] = st_r; g_halo_stamps[4 * tile + 2] = st_l;
+            g_halo_stamps[4 * tile + 3] = __builtin_amdgcn_s_memrealtime();
+        }
     }
 }
 
@@ -1169,7 +1193,15 @@ __global__ __launch_bounds__(512) void k_conv_img(
 
 // 5x5 halo kernel, 16-bit: four waves of 128 x 96 with a software-pipelined loop (1) or eight ping-pong waves of 64 x 96 (0)
 static bool g_halo4 = false;
-extern "C" int nvae_conv_halo4_enable(int on) { g_halo4 = on != 0; return NVAE_OK; }
+static int g_halo4_dbg = 0;
+extern "C" int nvae_conv_halo4_enable(int on) { g_halo4 = (on & 1) != 0; g_halo4_dbg = on >> 1; return NVAE_OK; }
+extern "C" int nvae_conv_halo_stamps(unsigned long long* host_out, int n) {
+    NVAE_REQUIRE(host_out && n > 0 && n <= 2048, "nvae_conv_halo_stamps: bad arguments");
+    hipError_t e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_halo_stamps), (size_t)n * sizeof(unsigned long long));
+    if (e != hipSuccess) NVAE_FAIL(NVAE_ELAUNCH, "nvae_conv_halo_stamps: %s", hipGetErrorString(e));
+    return NVAE_OK;
+}
 // whole-image kernel eligibility (must agree between the launcher and nvae_conv_gemm_stats_rows)
 static bool g_conv_img = true;
 extern "C" int nvae_conv_img_enable(int on) { g_conv_img = on != 0; return NVAE_OK; }
@@ -1308,6 +1340,8 @@ static int launch_conv_gemm(const NvaeConvGeom* g, const void* src, const void* 
     if (conv_halo_ok(dtype_of<T>(), g)) {
         const int pw = g->Win / 16, ppi = (g->Hin / 16) * pw;
         const int mt = g->B * ppi, nt = cdiv(N, 192);
+        const int vec_epi_plain = vec_epi;
+        const int vec_epi = vec_epi_plain | (g_halo4_dbg << 8);     // experiment bits ride in the high bits (0 in production)
         if (use_pre && g->Cin > PRE_MAXC_HALO) return 2;
 #define LAUNCH_HALO(KS_, WM_, F_, P_)                                                                     \
         hipLaunchKernelGGL((k_conv_halo<T, 192, KS_, WM_, F_, P_>), mt * nt, WM_ * 128, 0, s, *g, (const T*)src, \
