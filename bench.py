@@ -91,6 +91,7 @@ def time_dominant_kernel(model, batch, iters=20):
     return out
 
 
+PEAK_F32_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, 1/16 of the bf16 rate
 PEAK_HBM_GBPS = 8000.0           # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 
 
@@ -489,6 +490,7 @@ def main():
             with open(os.path.join(prof_dir, fam[-1])) as fh:
                 fam_json = json.load(fh)
         conv_calls = sum(v for k, v in census.counts.items() if k.startswith("nvae_conv_gemm"))
+        peak_tf = PEAK_F32_TFLOPS if args.dtype == "f32" else PEAK_BF16_TFLOPS      # dense MFMA peak of the arithmetic type
         n_calls = sum(census.counts.values())
         res = {
             "metric": "train_images_per_sec", "value": value, "unit": "images/s", "n_gpus": world,
@@ -502,10 +504,10 @@ def main():
                        "parallelism": f"dp{world}", "hip_graph": use_graph},
             "loss_nats": loss,
             "fwd_mac_per_image": macs,      # counted from this run's launches; SURVEY 8d: 6 949.4 M (dense + depthwise)
-            "e2e_mfma_frac": value / world * TRAIN_FLOP_PER_IMG / 1e12 / PEAK_BF16_TFLOPS,
-            "roofline": {"bound": "mfma", "kernel": "k_conv_halo<bf16,192,5> (dense 5x5 implicit GEMM of Postprocess, fwd + dgrad)",
-                         "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_BF16_TFLOPS, "traffic": traffic,
+            "e2e_mfma_frac": value / world * TRAIN_FLOP_PER_IMG / 1e12 / peak_tf,
+            "roofline": {"bound": "mfma", "kernel": f"k_conv_halo<{args.dtype},192,5> (dense 5x5 implicit GEMM of Postprocess, fwd + dgrad)",
+                         "achieved": achieved, "peak": peak_tf, "unit": "TFLOP/s",
+                         "frac": achieved / peak_tf, "traffic": traffic,
                          "traffic_unit": "bytes per launch (2*FETCH_SIZE + WRITE_SIZE, rocprofv3 --pmc)",
                          "traffic_source": traffic_src,
                          "algorithmic_bytes": 0.5 * (57704448 + 102506496),

@@ -140,6 +140,49 @@ def test_conv_fwd_bwd(lib, dev, dtype, case):
         assert rel_err(rv.g, dy64) < tol
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
+@pytest.mark.parametrize("shape", [(32, 16, 384), (16, 32, 192)], ids=["16x16_384", "32x32_192"])
+def test_conv_halo_forms_bit_identical(lib, dev, dtype, shape):
+    """The two 16-bit forms of the dense 5x5 halo kernel - eight ping-pong waves of 64 x 96 (production) and four
+    software-pipelined waves of 128 x 96 with AGPR-pinned accumulators (nvae_conv_halo4_enable(1)) - accumulate every output
+    element in the same order: outputs equal bit for bit in the three forms the step launches (plain, forward with the
+    statistics epilogue, data gradient with the BatchNorm-backward epilogue); the f32 slabs differ by the order of their
+    atomics only.  The 8-wave form is the one every other test checks against torch / the oracle."""
+    import ctypes as C_
+    from nvae_tf_amd import _lib as L_
+    B, hw, ci = shape
+    code = L_.dtype_code(dtype)
+    torch.manual_seed(3)
+    x = torch.randn(B, hw, hw, ci, device=dev).to(dtype)
+    w = (torch.randn(ci, 25 * ci, device=dev) / (25 * ci) ** 0.5).to(dtype)
+    g = L_.ConvGeom(B, hw, hw, ci, hw, hw, ci, 5, 5, 1, 2, 2, 1, 0, ci, ci, ci)
+    rows = lib.nvae_conv_gemm_stats_rows(code, C_.byref(g))
+    coef = torch.rand(4, ci, device=dev) + 0.5
+    outs = {}
+    try:
+        for form in (0, 1):
+            lib.nvae_conv_halo4_enable(form)
+            y0, y1, dx = (torch.full((B, hw, hw, ci), float("nan"), device=dev, dtype=dtype) for _ in range(3))
+            slab, part = torch.zeros(rows, 2, ci, device=dev), torch.zeros(rows, 2, ci, device=dev)
+            dgb, k0k1 = torch.zeros(2, ci, device=dev), torch.zeros(2, ci, device=dev)
+            f = L_.BnBwdFuse(L_.ptr(x), ci, L_.ACT_SWISH, 0, L_.ptr(coef[0]), L_.ptr(coef[1]), L_.ptr(coef[2]), L_.ptr(coef[3]),
+                             L_.ptr(part), None, L_.ptr(dgb[0]), L_.ptr(dgb[1]), L_.ptr(k0k1))
+            L_.call("nvae_conv_gemm", code, C_.byref(g), L_.ptr(x), L_.ptr(w), 25 * ci, None, None, L_.ptr(y0), 0, None)
+            L_.call("nvae_conv_gemm", code, C_.byref(g), L_.ptr(x), L_.ptr(w), 25 * ci, None, None, L_.ptr(y1), 0, L_.ptr(slab))
+            L_.call("nvae_conv_gemm_bnbwd", code, C_.byref(g), L_.ptr(x), L_.ptr(w), 25 * ci, None, None, L_.ptr(dx), C_.byref(f))
+            torch.cuda.synchronize()
+            outs[form] = (y0, y1, dx, slab, part)
+    finally:
+        lib.nvae_conv_halo4_enable(0)
+    a, b = outs[0], outs[1]
+    assert bool(torch.isfinite(b[0].float()).all()) and bool(torch.isfinite(b[2].float()).all())
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+    assert torch.equal(a[0], a[1])                     # the statistics epilogue does not touch the output
+    for p_, q_ in ((a[3], b[3]), (a[4], b[4])):
+        assert float((p_ - q_).abs().max() / p_.abs().max()) < 1e-5
+
+
 @pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16", "f16"])
 @pytest.mark.parametrize("shape", [(32, 4, 256, 40, 3), (16, 8, 128, 128, 3), (24, 4, 1536, 256, 1), (3, 8, 768, 72, 1)],
                          ids=lambda s: "B{}_H{}_{}-{}_k{}".format(*s))
@@ -382,11 +425,14 @@ FUSED_CHAIN_CASES = [
     # prologue next to the ping-pong wave schedule (16-bit), BatchNorm-backward dgrad epilogue; 5x5 and 3x3
     dict(B=64, H=16, ci=128, cm=192, co=192, k1=5, k2=5, halo=True),
     dict(B=64, H=16, ci=128, cm=192, co=192, k1=3, k2=3, halo=True),
+    # the same 5x5 chain on the four-wave software-pipelined form of the halo kernel (nvae_conv_halo4_enable)
+    dict(B=64, H=16, ci=128, cm=192, co=192, k1=5, k2=5, halo=True, halo4=True),
 ]
 
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16", "f16"])
-@pytest.mark.parametrize("case", FUSED_CHAIN_CASES, ids=lambda c: "B{B}_H{H}_{ci}-{cm}-{co}_k{k1}{k2}".format(**c))
+@pytest.mark.parametrize("case", FUSED_CHAIN_CASES,
+                         ids=lambda c: "B{B}_H{H}_{ci}-{cm}-{co}_k{k1}{k2}".format(**c) + ("_4wave" if c.get("halo4") else ""))
 @pytest.mark.parametrize("mode", ["prologue+fin", "prologue", "materialised"])
 def test_fused_bn_chain(lib, dev, dtype, case, mode, monkeypatch):
     """conv -> BN(+Swish) -> conv against torch autograd (fp64) at every conv tile configuration.
@@ -400,6 +446,7 @@ def test_fused_bn_chain(lib, dev, dtype, case, mode, monkeypatch):
     from nvae_tf_amd.params import ParamStore
     monkeypatch.setattr(ops, "CONV_PRE", "all")        # (the product enables the prologue only where it measured faster)
     monkeypatch.setattr(ops, "STATS_FIN", True)
+    lib.nvae_conv_halo4_enable(1 if case.get("halo4") else 0)
     B, H, ci, cm, co, k1, k2 = (case[n] for n in ("B", "H", "ci", "cm", "co", "k1", "k2"))
     g = torch.Generator().manual_seed(77)
     ps = ParamStore(seed=5)

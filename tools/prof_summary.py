@@ -12,7 +12,7 @@ print(f"total kernel time {tot/1e6:.2f} ms over the run = {tot/1e6/steps:.2f} ms
 FAM = [("conv_halo", r"k_conv_halo"), ("wgrad_halo", r"k_wgrad_halo"), ("conv_gemm2", r"k_conv_gemm2|k_conv_img"),
        ("conv wgrad (small) + slab reduce", r"k_conv_wgrad2|k_slab_reduce|k_conv_smallk|k_conv_1ch|k_conv_thin|k_conv_direct"),
        ("BN family", r"k_bn_|k_stripreduce"), ("SE", r"k_se_"), ("depthwise", r"k_dw5"),
-       ("SN + prep + Adamax", r"k_sn_|k_weight_prep|k_adamax"), ("RCCL", r"ccl|Ccl|CCL"),
+       ("SN + prep + Adamax", r"k_sn_|k_weight_prep|k_adamax"), ("RCCL", r"[nr]ccl(?!r)|Ccl|CCL"),
        ("loss / sampler / elementwise", r".")]
 fam = collections.OrderedDict((n, [0, 0.0]) for n, _ in FAM)
 for r in rows:
