@@ -291,7 +291,7 @@ __global__ __launch_bounds__(512) void k_wgrad_halo(NvaeConvGeom g, const T* __r
                                                     const T* __restrict__ dy, float* dw, int dw_ld,
                                                     int n_tiles, int cchunks, int hp_per_split,
                                                     int hp_w /*W/16*/, int hp_per_img /*(H/8)*(W/16)*/,
-                                                    int hp_total, const uint4* __restrict__ zeros, int dbg) {
+                                                    int hp_total, const uint4* __restrict__ zeros) {
     constexpr int NT = 512, NTL = 192, CCH = 64;
     constexpr int HW_ = 16 + KS - 1;                     // halo width in pixels
     constexpr int HWL = 32;                              // halo row pitch in LDS (pixels): a power of two keeps
@@ -396,9 +396,9 @@ __global__ __launch_bounds__(512) void k_wgrad_halo(NvaeConvGeom g, const T* __r
     if (nsteps > 0) issue(0, hp_begin);
     for (int s = 0; s < nsteps; ++s) {
         wait_vmcnt<0>();
-        if (!(dbg & 2)) __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (s + 1 < nsteps && !(dbg & 1)) issue((s + 1) & 1, hp_begin + s + 1);
+        if (s + 1 < nsteps) issue((s + 1) & 1, hp_begin + s + 1);
         const unsigned char* bufA = lds + (s & 1) * STAGE_BYTES;
         const unsigned char* bufB = bufA + A_BYTES;
 #pragma unroll
@@ -455,9 +455,6 @@ static bool wgrad_halo_ok(int dtype, const NvaeConvGeom* g, const float* db) {
            (long)g->B * g->Hin * g->Win >= 16384;
 }
 
-static int g_wgrad_dbg = 0;      // EXPERIMENT
-extern "C" int nvae_conv_wgrad_debug(int v) { g_wgrad_dbg = v; return 0; }
-
 template <typename T>
 static void launch_wgrad_halo(const NvaeConvGeom* g, const void* x, const void* dy, float* dw, int dw_ld,
                               hipStream_t s) {
@@ -473,10 +470,10 @@ static void launch_wgrad_halo(const NvaeConvGeom* g, const void* x, const void* 
     const uint4* zeros = zero_page();
     if (KS == 5)
         hipLaunchKernelGGL((k_wgrad_halo<T, 5>), grid, 512, 0, s, *g, (const T*)x, (const T*)dy, dw, dw_ld, n_tiles,
-                           cchunks, hps, hp_w, hp_per_img, hp_total, zeros, g_wgrad_dbg);
+                           cchunks, hps, hp_w, hp_per_img, hp_total, zeros);
     else
         hipLaunchKernelGGL((k_wgrad_halo<T, 3>), grid, 512, 0, s, *g, (const T*)x, (const T*)dy, dw, dw_ld, n_tiles,
-                           cchunks, hps, hp_w, hp_per_img, hp_total, zeros, g_wgrad_dbg);
+                           cchunks, hps, hp_w, hp_per_img, hp_total, zeros);
 }
 
 // Split policy shared by the launcher and the scratch-size query.

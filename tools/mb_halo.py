@@ -137,20 +137,3 @@ if "--phases" in sys.argv:
             t0 = a[:, 0].min()
             print(f"   {hw}x{hw} {nm:>12s}: wall {wall:6.1f} us | first entry -> last exit {a[:, 3].max() - t0:6.1f} | per workgroup (median): prologue {np.median(a[:, 1] - a[:, 0]):5.1f}  "
                   f"loop {np.median(a[:, 2] - a[:, 1]):6.1f}  epilogue {np.median(a[:, 3] - a[:, 2]):5.1f} | entry spread {a[:, 0].max() - t0:5.1f}  last loop end {a[:, 2].max() - t0:6.1f}", flush=True)
-
-if "--wgrad" in sys.argv:
-    lib.nvae_conv_wgrad_debug.restype = C.c_int
-    for hw, ci in ((16, 384), (32, 192)):
-        x = torch.randn(B, hw, hw, ci, device=dev).to(dt)
-        dy = torch.randn(B, hw, hw, ci, device=dev).to(dt)
-        g = L.ConvGeom(B, hw, hw, ci, hw, hw, ci, 5, 5, 1, 2, 2, 1, 0, ci, ci, ci)
-        dw = torch.zeros(25 * ci, ci, device=dev)
-        fn = lambda: L.call("nvae_conv_wgrad", code, C.byref(g), L.ptr(x), L.ptr(dy), L.ptr(dw), ci, None, None, 0)
-        graphs = {}
-        for bits in (0, 1, 2, 3):
-            lib.nvae_conv_wgrad_debug(bits)
-            graphs[bits] = chain(fn)
-        lib.nvae_conv_wgrad_debug(0)
-        flops = 2.0 * B * hw * hw * 25 * ci * ci
-        for k, v in time_graphs(graphs).items():
-            print(f"   wgrad {hw}x{hw} {ci}: experiment bits {k} (1 = no DMA in the loop, 2 = no barrier): {v:7.1f} us  {flops / v / 1e6:6.0f} TFLOP/s", flush=True)
