@@ -676,8 +676,13 @@ __global__ __launch_bounds__(WM * 128) void k_conv_halo(
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave - wm * WN;
-    const int tile = xcd_remap(blockIdx.x, total_tiles);
-    const int bp = tile / n_tiles, bn = tile - bp * n_tiles;
+    // (PMC rounds 1-3: 110 MB per launch at 16x16x384 = 1.90x the algorithmic bytes.  The excess is L2 FILL traffic, served by
+    // the Infinity Cache: eight XCD-private L2s each pull both 3.7 MB weight panels.  Giving every XCD one panel - bn = XCD % 2 -
+    // was measured in round 3: weights 59 -> 30 MB, but the two N-tiles of a patch then sit on different XCDs and its
+    // activations are pulled twice, 25 -> 50 MB: 1.83x, same time.  With two N-tiles one operand is duplicated either way.)
+    const int tile_ = xcd_remap(blockIdx.x, total_tiles);
+    const int bp = tile_ / n_tiles, bn = tile_ - bp * n_tiles;
+    const int tile = bp * n_tiles + bn;
     const int b = bp / patches_per_img, pidx = bp - b * patches_per_img;
     const int py0 = (pidx / patches_w) * 16, px0 = (pidx % patches_w) * 16;
     const int N = g.Cout, H = g.Hin, W = g.Win;
