@@ -128,7 +128,7 @@ def test_train_step_parity(lib, dev, dtype, ltol, gtol):
         # r03_bf16_spread.txt: SE parameters of cells where a hidden unit sits at its ReLU kink, and the BatchNorm in
         # front of that SE).  Everything else - and the distribution as a whole - keeps the tight bound.
         orc.steps = 100
-        spread = bf16_spread(orc, snap, x, eps, out_o["grads"], runs=4)
+        spread = bf16_spread(orc, snap, x, eps, out_o["grads"], runs=8)
         widened = sorted(((v, k) for k, v in spread.items() if 2 * v > gtol), reverse=True)
         print("tensors whose own bf16 spread exceeds gtol / 2 (bound widened to 2 x spread):", widened[:12])
         assert len(widened) <= 8, widened        # measured: 5 (post.cell0.se.b1 / se.w1 / bn3.beta, pre.cell0.se.w1 / se.b1)
@@ -395,7 +395,7 @@ def test_odd_batch_sizes_run_and_match_eager_graph(lib, dev, batch):
     assert abs(float(out_a["loss"]) - float(out_b["loss"])) / abs(float(out_a["loss"])) < 2e-3
 
 
-@pytest.mark.parametrize("batch", [2] + ([6] if __import__("os").environ.get("NVAE_TEST_C2_BATCH6") else []))
+@pytest.mark.parametrize("batch", [2, 6])
 def test_c2_architecture_parity(lib, dev, batch):
     """BASELINE.json configs[1] architecture at full width and depth (groups [5,10], 2 cells per group,
     62 225 021 parameters, 15 latent groups): f32 HIP path vs the fp64 oracle - losses, all 15 per-group KLs,
