@@ -409,8 +409,8 @@ def test_c2_architecture_parity(lib, dev, batch):
     meet 1e-3 / 0.9999 there.  The strict bounds are therefore asserted at batch 2, where the problem is two
     orders of magnitude better conditioned, and a larger batch (6: 96 samples per channel in the 4x4 BatchNorms; 8 in
     tests/diag/diag_c2b.py - the fp64 oracle needs 80 s there, more than the suite can afford) checks the same quantities
-    against bounds a few times the f32 oracle's own distance.  (Round 3: the batch-6 arm costs 80-150 s of CPU oracle time
-    and only runs with NVAE_TEST_C2_BATCH6=1; the suite has to fit the GPU box's time limit.)"""
+    against bounds a few times the f32 oracle's own distance.  (The oracle passes took minutes on the GPU boxes while torch used every
+    core the box SHOWS instead of the 16 it grants; tests/conftest.py caps the threads and both arms take seconds.)"""
     cfg = dict(CFG, n_encoder_channels=32, n_decoder_channels=32, res_cells_per_group=2, n_preprocess_cells=3,
                n_post_process_cells=3, n_groups_per_scale=[5, 10])
     global B
