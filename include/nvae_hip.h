@@ -138,6 +138,9 @@ int nvae_conv_gemm_force_split(int S);
 int nvae_conv_img_ok(int dtype, const NvaeConvGeom* g);
 /* Tuning / test hook: 0 = never select the whole-image kernel (the generic implicit GEMM runs instead). */
 int nvae_conv_img_enable(int on);
+/* which kernel nvae_conv_gemm* picks for a geometry: -1 whole-image kernel, -2 halo kernel, else k_conv_gemm2's tile family
+ * (1: 256x192, 2: 128x192, 3: 128x128, 4: 128x64, 5: 32x64, 6 / 7: 64x64, 14: 128x128 with two workgroups per CU) */
+int nvae_conv_gemm_family(int dtype, const NvaeConvGeom* g);
 /* 16-bit dense 5x5 halo kernel: 1 = four waves of 128 x 96 with a software-pipelined loop, 0 = eight ping-pong waves of
  * 64 x 96.  Results are bit-identical (same accumulation order per output element). */
 int nvae_conv_halo4_enable(int on);

@@ -71,6 +71,7 @@ _SIGS = {
     "nvae_conv_set_workspace": None,
     "nvae_conv_img_ok": None,
     "nvae_conv_img_enable": None,
+    "nvae_conv_gemm_family": None,
     "nvae_conv_halo4_enable": None,
     "nvae_conv_halo_stamps": None,
     "nvae_conv_gemm_bnbwd": [_i, _p, _p, _p, _i, _p, _p, _p, _p],
@@ -192,6 +193,8 @@ def load():
     lib.nvae_conv_img_ok.argtypes = [_i, _G]
     lib.nvae_conv_img_enable.restype = C.c_int
     lib.nvae_conv_img_enable.argtypes = [_i]
+    lib.nvae_conv_gemm_family.restype = C.c_int
+    lib.nvae_conv_gemm_family.argtypes = [_i, C.c_void_p]
     lib.nvae_conv_halo4_enable.restype = C.c_int
     lib.nvae_conv_halo4_enable.argtypes = [_i]
     lib.nvae_conv_halo_stamps.restype = C.c_int

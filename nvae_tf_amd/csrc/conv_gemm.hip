@@ -45,6 +45,7 @@ struct ConvBnBwd {
 // (optional): the activated tensor is written once, by the one N-tile workgroup whose turn it is, for the
 // weight-gradient kernel of the same conv (which runs much later, on the side stream).
 #define PRE_MAXC 2048            // channels of the coefficient table in LDS (k_conv_gemm2)
+#define PRE_MAXC_2CU 512         // (k_conv_gemm2's two-workgroups-per-CU family)
 #define PRE_MAXC_HALO 512        // (k_conv_halo: 152 KB of its 160 KB are the ring)
 struct ConvPre {
     BnFromSlab bn;              // final coefficient table, or the statistics slab to finish in-kernel (bn_fin.h)
@@ -360,7 +361,7 @@ __device__ __forceinline__ void conv_epilogue(f32x4 (&acc)[BM / WM / 16][BN / WN
 //   LDS-DMA needs every lane to write its slot.
 // =========================================================================================
 template <typename T, int BM, int BN, int WM, int WN, int STAGES, int BKC, bool BNBWD, bool PRE>
-__global__ __launch_bounds__(WM* WN * 64) void k_conv_gemm2(
+__global__ __launch_bounds__(WM* WN * 64, (STAGES == 2 && BM == 128) ? 2 : 1) void k_conv_gemm2(
     NvaeConvGeom g, const T* __restrict__ src, const T* __restrict__ wT, int w_ld,
     const float* __restrict__ bias, const T* residual, void* out, int out_f32, int M, int K, int n_tiles,
     int total_tiles, FastDiv fd_hw, FastDiv fd_w, const uint4* __restrict__ zeros, float* stats,
@@ -380,7 +381,10 @@ __global__ __launch_bounds__(WM* WN * 64) void k_conv_gemm2(
                   "BN-backward scratch must fit in the ring");
     static_assert(STAGES >= 2 && STAGES <= 6, "ring depth");
     __shared__ uint4 lds[STAGES * STAGE];
-    __shared__ __attribute__((aligned(16))) float pre_tab[PRE ? 2 * PRE_MAXC : 4];   // [scale | shift] of the prologue
+    // (the 2-deep 128-row family is sized for TWO workgroups per CU - short-K layers whose time is prologue + epilogue: one
+    //  workgroup's stores overlap the other's loads - so its coefficient table is small: K <= 512 means Cin <= 512)
+    constexpr int PTC = (STAGES == 2 && BM == 128) ? PRE_MAXC_2CU : PRE_MAXC;
+    __shared__ __attribute__((aligned(16))) float pre_tab[PRE ? 2 * PTC : 4];   // [scale | shift] of the prologue
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -470,7 +474,7 @@ __global__ __launch_bounds__(WM* WN * 64) void k_conv_gemm2(
     issue(0);
     if constexpr (PRE) {
         // (behind the first stage's DMA: the slab -> coefficient chain is a dependent global round trip + f64 arithmetic)
-        for (int c = tid; c < g.Cin; c += NT) bn_coef<sizeof(T) == 4>(pre.bn, g.Cin, c, blockIdx.x == 0, pre_tab[c], pre_tab[PRE_MAXC + c]);
+        for (int c = tid; c < g.Cin; c += NT) bn_coef<sizeof(T) == 4>(pre.bn, g.Cin, c, blockIdx.x == 0, pre_tab[c], pre_tab[PTC + c]);
         __syncthreads();
     }
 #pragma unroll
@@ -495,7 +499,7 @@ __global__ __launch_bounds__(WM* WN * 64) void k_conv_gemm2(
                 const int hc = hb[i] + p_kh, wc = wb[i] + p_kw;
                 if (mv[i] && kval && hc >= 0 && hc < hlim && wc >= 0 && wc < wlim) {
                     uint4* slot = lds + cur * STAGE + tid + NT * i;
-                    const uint4 v = pre_chunk<T>(*slot, pre_tab + p_ci, pre_tab + PRE_MAXC + p_ci, pre.act);
+                    const uint4 v = pre_chunk<T>(*slot, pre_tab + p_ci, pre_tab + PTC + p_ci, pre.act);
                     *slot = v;
                     if (my_turn) *(uint4*)((T*)pre.act_out + (pb[i] + (long)hc * g.Win + wc) * pre.act_ld + p_ci) = v;
                 }
@@ -1232,6 +1236,7 @@ static bool conv_halo_ok(int dtype, const NvaeConvGeom* g) {
 
 // Tile family of the generic kernel for a geometry (tools/tune_conv.py sweeps them on the tower shapes):
 //  1: 256x192 (2-deep ring)  2: 128x192  3: 128x128  4: 128x64  5: 32x64, 128-deep steps  6: 64x64, 128-deep  7: 64x64
+//  14: 128x128, 2-deep ring, two workgroups per CU (8-13: experimental, nvae_conv_gemm_force_tile only)
 static int conv_tile_family(const NvaeConvGeom* g) {
     const int M = g->B * g->Hout * g->Wout, K = g->KH * g->KW * g->Cin, N = g->Cout;
     const long big_tiles = (long)cdiv(M, 128) * cdiv(N, 128);
@@ -1242,6 +1247,10 @@ static int conv_tile_family(const NvaeConvGeom* g) {
     // large problems: 128-row tiles, 8 waves; N tile with the least padding (ties -> larger).  With a short K loop
     // (K < 512) the 128-row tiles need twice the tiles to beat 64 x 64 (256 -> 1536 at 4x4: 10.2 vs 7.7 us)
     if (big_tiles >= (K < 512 ? 256 : 192)) {
+        // short K loop and at least two rounds of workgroups: these launches are prologue + epilogue (C4's 256 -> 1536 1x1 convs
+        // at 16x16: 4 ring steps, then 48 KB of stores per tile), and a 3-deep 128 x 192 ring (123 KB) leaves one workgroup per
+        // CU, so nothing overlaps them.  128 x 128 with a 2-deep ring is 70 KB: two workgroups per CU
+        if (K <= 512 && big_tiles >= 512 && w128 <= w64) return 14;
         if (w192 <= w128 && w192 <= w64) return 2;
         if (w128 <= w64) return 3;
         return 4;
@@ -1257,7 +1266,7 @@ static int conv_tile_family(const NvaeConvGeom* g) {
 
 static int conv_gemm_bm_noimg(int dtype, const NvaeConvGeom* g) {
     if (conv_halo_ok(dtype, g)) return 256;
-    static const int bm[8] = {0, 256, 128, 128, 128, 32, 64, 64};
+    static const int bm[15] = {0, 256, 128, 128, 128, 32, 64, 64, 0, 0, 0, 0, 0, 0, 128};
     return bm[conv_tile_family(g)];
 }
 static int conv_gemm_bm(int dtype, const NvaeConvGeom* g) {
@@ -1266,6 +1275,13 @@ static int conv_gemm_bm(int dtype, const NvaeConvGeom* g) {
     return conv_gemm_bm_noimg(dtype, g);
 }
 
+// which kernel a geometry gets (tests): -1 whole-image kernel, -2 halo kernel, else the tile family of k_conv_gemm2
+extern "C" int nvae_conv_gemm_family(int dtype, const NvaeConvGeom* g) {
+    if (!g) return 0;
+    if (is16(dtype) && conv_img_ok(dtype, g)) return -1;
+    if (conv_halo_ok(dtype, g)) return -2;
+    return conv_tile_family(g);
+}
 // tuning hook (tools/tune_conv.py): 0 = the launcher's own choice, 1..7 = force a tile family of k_conv_gemm2
 static int g_force_tile = 0;
 extern "C" int nvae_conv_gemm_force_tile(int t) { g_force_tile = t; return NVAE_OK; }
@@ -1396,7 +1412,8 @@ static int launch_conv_gemm(const NvaeConvGeom* g, const void* src, const void* 
     { if (be.x) LAUNCH2F(BM_, BN_, WM_, WN_, ST_, BKC_, true, false)                                    \
       else LAUNCH2F(BM_, BN_, WM_, WN_, ST_, BKC_, false, false) }
     int pick = (g_force_tile && !be.x) ? g_force_tile : family;
-    if (pick >= 8 && use_pre) pick = family;
+    if (pick >= 8 && pick <= 13 && use_pre) pick = family;
+    if (pick == 14 && use_pre && g->Cin > PRE_MAXC_2CU) pick = 3;
     switch (pick) {
         case 8: LAUNCH2X(32, 64, 2, 4, 4, 16) break;
         case 9: LAUNCH2X(32, 64, 2, 4, 6, 16) break;
@@ -1404,6 +1421,7 @@ static int launch_conv_gemm(const NvaeConvGeom* g, const void* src, const void* 
         case 11: LAUNCH2X(32, 64, 2, 2, 6, 8) break;
         case 12: LAUNCH2X(64, 128, 2, 4, 3, 16) break;
         case 13: LAUNCH2X(64, 128, 2, 4, 4, 8) break;
+        case 14: LAUNCH2(128, 128, 2, 4, 2, 8) break;
         case 1: LAUNCH2(256, 192, 4, 2, 2, 8) break;
         case 2: LAUNCH2(128, 192, 2, 4, 3, 8) break;
         case 3: LAUNCH2(128, 128, 2, 4, 3, 8) break;

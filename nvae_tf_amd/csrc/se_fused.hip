@@ -824,7 +824,7 @@ extern "C" int nvae_se_fused_bwd(int dtype, const void* x, const float* bn_scale
         DISPATCH_T(dtype, hipLaunchKernelGGL((k_se_split_bwd<T, N_>), B * S, 256, 0, (hipStream_t)stream, (const T*)x, bn_scale, \
                                              bn_shift, act, (const T*)dy, gate, hidden, (T*)dx, (T*)dskip, B, HW, C, Hd,    \
                                              w1, w2, skip_scale, branch_scale, acc_dx, dskip ? acc_dskip : 0, scratch, so, sp);)
-        if (nch == 1) SEF_LAUNCH(1) else if (nch == 2) SEF_LAUNCH(2) else if (nch == 4) SEF_LAUNCH(4) else SEF_LAUNCH(0)
+        if (nch == 1) SEF_LAUNCH(1) else if (nch == 2) SEF_LAUNCH(2) else if (nch == 4) SEF_LAUNCH(4) else if (nch == 8) SEF_LAUNCH(8) else SEF_LAUNCH(0)
 #undef SEF_LAUNCH
         NVAE_LAUNCH_CHECK("se_fused_bwd (split)");
         return NVAE_OK;

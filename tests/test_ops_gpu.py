@@ -64,6 +64,7 @@ CONV_CASES = [
     dict(k=3, cin=24, cout=40, stride=1, up=1, H=4, B=5, residual=True),
     dict(k=5, cin=192, cout=192, stride=1, up=1, H=8, B=2, bias=False),
     dict(k=5, cin=128, cout=192, stride=1, up=1, H=32, B=16),     # halo-tile kernel (16x16 patches), 5x5
+    dict(k=1, cin=64, cout=512, stride=1, up=1, H=32, B=16, family=14),   # short K, 512 tiles: 128x128, two workgroups per CU
     dict(k=3, cin=128, cout=200, stride=1, up=1, H=16, B=64),     # halo-tile kernel, 3x3, ragged N
     dict(k=5, cin=128, cout=192, stride=1, up=1, H=32, B=16, bias=False),   # + halo weight-gradient kernel
     dict(k=3, cin=64, cout=384, stride=1, up=1, H=16, B=64, bias=False),    # halo wgrad, 3x3, two n-tiles
@@ -126,6 +127,11 @@ def test_conv_fwd_bwd(lib, dev, dtype, case):
         from nvae_tf_amd import _lib as L_
         gg = L_.ConvGeom(B, H, H, cin, H, H, cout, 3, 3, 1, 1, 1, 1, 0, cin, cout, cout)
         assert lib.nvae_conv_img_ok(L_.dtype_code(dtype), C_.byref(gg)) == (0 if dtype == torch.float32 else 1)
+    if case.get("family"):
+        import ctypes as C_
+        from nvae_tf_amd import _lib as L_
+        gg = L_.ConvGeom(B, H, H, cin, H, H, cout, k, k, 1, (k - 1) // 2, (k - 1) // 2, 1, 0, cin, cout, cout)
+        assert lib.nvae_conv_gemm_family(L_.dtype_code(dtype), C_.byref(gg)) == case["family"]
     y = ops.conv2d(ctx, xv, conv, **kw)
     y.g = dy.to(dev, dtype)
     ctx.backward()
@@ -425,6 +431,10 @@ FUSED_CHAIN_CASES = [
     # prologue next to the ping-pong wave schedule (16-bit), BatchNorm-backward dgrad epilogue; 5x5 and 3x3
     dict(B=64, H=16, ci=128, cm=192, co=192, k1=5, k2=5, halo=True),
     dict(B=64, H=16, ci=128, cm=192, co=192, k1=3, k2=3, halo=True),
+    # short-K 1x1 layers on many pixels: the two-workgroups-per-CU family (14) with the operand prologue (first case: the
+    # second conv's forward) and with the BatchNorm-backward epilogue (second case: its data gradient)
+    dict(B=16, H=32, ci=32, cm=128, co=512, k1=1, k2=1, fam14="fwd"),
+    dict(B=16, H=32, ci=32, cm=512, co=128, k1=1, k2=1, fam14="dgrad"),
     # the same 5x5 chain on the four-wave software-pipelined form of the halo kernel (nvae_conv_halo4_enable)
     dict(B=64, H=16, ci=128, cm=192, co=192, k1=5, k2=5, halo=True, halo4=True),
 ]
@@ -448,6 +458,13 @@ def test_fused_bn_chain(lib, dev, dtype, case, mode, monkeypatch):
     monkeypatch.setattr(ops, "STATS_FIN", True)
     lib.nvae_conv_halo4_enable(1 if case.get("halo4") else 0)
     B, H, ci, cm, co, k1, k2 = (case[n] for n in ("B", "H", "ci", "cm", "co", "k1", "k2"))
+    if case.get("fam14"):
+        import ctypes as C_
+        from nvae_tf_amd import _lib as L_
+        # forward GEMM of the second conv (K = cm, N = co) resp. its data gradient (K = co, N = cm)
+        kk, nn = (cm, co) if case["fam14"] == "fwd" else (co, cm)
+        gg = L_.ConvGeom(B, H, H, kk, H, H, nn, 1, 1, 1, 0, 0, 1, 0, kk, nn, nn)
+        assert lib.nvae_conv_gemm_family(L_.dtype_code(dtype), C_.byref(gg)) == 14
     g = torch.Generator().manual_seed(77)
     ps = ParamStore(seed=5)
     c1 = ps.conv("c1", k1, ci, cm, bias=False)
