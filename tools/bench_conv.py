@@ -35,6 +35,10 @@ def main():
     dtype = torch.float32 if "f32" in sys.argv else torch.bfloat16
     dev = torch.device("cuda:0")
     print(f"{'shape':40s} {'fwd us':>9s} {'TF':>7s} {'bwd(dgrad+wgrad) us':>20s} {'TF':>7s}")
+    ft = [a for a in sys.argv[1:] if a.startswith("--force-tile=")]      # k_conv_gemm2 tile family (nvae_conv_gemm_force_tile)
+    if ft:
+        from nvae_tf_amd import _lib as L
+        L.load().nvae_conv_gemm_force_tile(int(ft[0].split("=")[1]))
     only = [a for a in sys.argv[1:] if a.startswith("--only=")]
     shapes = SHAPES
     if only:
