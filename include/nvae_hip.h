@@ -43,7 +43,7 @@ extern "C" {
 
 /* Bumped whenever an entry point is added or a signature changes; the Python binding (nvae_tf_amd/_lib.py
  * ABI_VERSION) refuses to load a library that reports another value. */
-#define NVAE_ABI_VERSION 4
+#define NVAE_ABI_VERSION 5
 
 const char* nvae_last_error(void);
 int nvae_abi_version(void);
