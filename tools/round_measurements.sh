@@ -1,3 +1,7 @@
+#!/bin/bash
+# usage (on the GPU box): bash tools/round_measurements.sh   -> gpurun_out/r03_bench_*.json, prof_* summaries
+# The round's committed measurements: default bench line (with the CPU baseline), rocprofv3 summaries of the C2 / C4 / C5 steps,
+# C1, forced-DP, float16 / float32 and C5-in-float16 lines.  Copy what is to be judged into profiles/.
 set -x
 cd $GRAFT_REPO_ROOT
 timeout -k 10 400 python bench.py > gpurun_out/r03_bench_default.json 2> gpurun_out/r03_bench_default.err || exit 1
