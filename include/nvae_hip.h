@@ -45,6 +45,14 @@ extern "C" {
  * ABI_VERSION) refuses to load a library that reports another value. */
 #define NVAE_ABI_VERSION 5
 
+/* Deterministic mode (NVAE_DETERMINISTIC=1 in the Python host, read by _lib.load()).  With on != 0 every sum across
+ * workgroups has ONE adder per address or a fixed order, so the bits a step produces do not depend on workgroup scheduling:
+ * one statistics-slab row per producing workgroup (the *_rows queries return the larger counts: call this BEFORE sizing
+ * slabs), weight-gradient pixel splits combined through slabs or not split, no halo weight-gradient kernel, an ordered
+ * BatchNorm-regulariser sum.  Slower (ordered sums of up to 1 024 slab rows; unsplit depthwise / small weight gradients). */
+int nvae_set_deterministic(int on);
+int nvae_get_deterministic(void);
+
 const char* nvae_last_error(void);
 int nvae_abi_version(void);
 

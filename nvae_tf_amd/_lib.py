@@ -71,6 +71,8 @@ _SIGS = {
     "nvae_conv_set_workspace": None,
     "nvae_conv_img_ok": None,
     "nvae_conv_img_enable": None,
+    "nvae_set_deterministic": None,
+    "nvae_get_deterministic": None,
     "nvae_conv_gemm_family": None,
     "nvae_conv_halo4_enable": None,
     "nvae_conv_halo_stamps": None,
@@ -193,6 +195,10 @@ def load():
     lib.nvae_conv_img_ok.argtypes = [_i, _G]
     lib.nvae_conv_img_enable.restype = C.c_int
     lib.nvae_conv_img_enable.argtypes = [_i]
+    lib.nvae_set_deterministic.restype = C.c_int
+    lib.nvae_set_deterministic.argtypes = [_i]
+    lib.nvae_get_deterministic.restype = C.c_int
+    lib.nvae_get_deterministic.argtypes = []
     lib.nvae_conv_gemm_family.restype = C.c_int
     lib.nvae_conv_gemm_family.argtypes = [_i, C.c_void_p]
     lib.nvae_conv_halo4_enable.restype = C.c_int
@@ -211,6 +217,10 @@ def load():
         fn = getattr(lib, name)
         fn.restype = C.c_int
         fn.argtypes = [*sig, _p]
+    # NVAE_DETERMINISTIC=1: ordered cross-workgroup sums everywhere (include/nvae_hip.h, nvae_set_deterministic); set before any
+    # slab is sized.  Bit-identical steps for identical inputs and state, at a price in speed.
+    if os.environ.get("NVAE_DETERMINISTIC", "0") not in ("", "0"):
+        lib.nvae_set_deterministic(1)
     _lib = lib
     return lib
 

@@ -386,6 +386,7 @@ extern "C" int nvae_colsum(int dtype, const void* x, long rows, int C, int ld, f
     NVAE_REQUIRE(rows > 0 && ld >= C && ld % 8 == 0 && aligned16(x), "colsum: bad rows/ld/alignment");
     int S = nvae_reduce_splits(rows, C);
     if (S > 8) S = 8;   // atomics: keep the adders per address few
+    if (g_nvae_det) S = 1;
     DISPATCH_T(dtype, launch_strip<T, 4>((const T*)x, nullptr, 1, rows, C, ld, S, nullptr, nullptr, 0, out, (hipStream_t)stream);)
     NVAE_LAUNCH_CHECK("colsum");
     return NVAE_OK;

@@ -33,9 +33,17 @@ extern thread_local char g_nvae_err[512];
     } while (0)
 
 static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+
+// NVAE_DETERMINISTIC (nvae_set_deterministic): every sum across workgroups then has ONE adder per address or a fixed order, so
+// a step's results do not depend on how the hardware schedules workgroups.  The launchers pick their slow-but-ordered
+// configurations: one statistics-slab row per producing workgroup, pixel splits of the weight-gradient kernels combined
+// through slabs or not split at all, no halo weight-gradient kernel (its pixel splits meet in f32 atomics).
+extern int g_nvae_det;
 static inline bool is16(int dtype) { return dtype == NVAE_BF16 || dtype == NVAE_F16; }     // 16-bit activation types
 template <typename T> static constexpr int dtype_of() { return sizeof(T) == 4 ? NVAE_F32 : (__is_same(T, __bf16) ? NVAE_BF16 : NVAE_F16); }
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+// rows of a statistics slab that `producers` workgroups add into: <= 64 adders per address, or one each (deterministic)
+static inline int slab_rows_for(long producers) { return g_nvae_det ? (int)(producers > 0 ? producers : 1) : cdiv(producers, 64); }
 
 // ---------------------------------------------------------------------------------------
 // 8-element vector access: one 16-B access for bf16, two for f32.

@@ -501,7 +501,8 @@ extern "C" int nvae_conv_direct_wgrad(int dtype, const NvaeConvGeom* g, const vo
     NVAE_REQUIRE(blocks < (1L << 31), "conv_direct_wgrad: too many weights");
     {
         bool done = false;
-        DISPATCH_T(dtype, done = launch_thin_wgrad<T>(g, x, dy, dw, dw_ld, db, (hipStream_t)stream);)
+        // (deterministic mode: the generic kernel below has one workgroup, i.e. one adder, per weight)
+        if (!g_nvae_det) { DISPATCH_T(dtype, done = launch_thin_wgrad<T>(g, x, dy, dw, dw_ld, db, (hipStream_t)stream);) }
         if (done) {
             NVAE_LAUNCH_CHECK("conv_thin_wgrad");
             return NVAE_OK;

@@ -1331,7 +1331,7 @@ static int launch_conv_gemm(const NvaeConvGeom* g, const void* src, const void* 
     // 16-column tiles): then the generic kernel runs on a slab the host sized for 128-row tiles (fewer rows, more adders)
     const bool img_run = sizeof(T) == 2 && conv_img_ok(dtype_of<T>(), g) && !sfin.counter && !be.fin.counter;
     be.m_tiles = cdiv((long)g->B * g->Hout * g->Wout, img_run ? 128 : conv_gemm_bm_noimg(dtype_of<T>(), g));
-    be.rows = cdiv(cdiv((long)g->B * g->Hout * g->Wout, conv_gemm_bm(dtype_of<T>(), g)), 64);
+    be.rows = slab_rows_for(cdiv((long)g->B * g->Hout * g->Wout, conv_gemm_bm(dtype_of<T>(), g)));
     const int M = g->B * g->Hout * g->Wout, K = g->KH * g->KW * g->Cin, N = g->Cout;
     FastDiv fd_hw = make_fastdiv((unsigned)(g->Hout * g->Wout)), fd_w = make_fastdiv((unsigned)g->Wout);
     const uint4* zeros = zero_page();
@@ -1441,7 +1441,7 @@ extern "C" int nvae_conv_img_ok(int dtype, const NvaeConvGeom* g) { return g && 
 
 extern "C" int nvae_conv_gemm_stats_rows(int dtype, const NvaeConvGeom* g) {
     if (!g) return 0;
-    return cdiv(cdiv((long)g->B * g->Hout * g->Wout, conv_gemm_bm(dtype, g)), 64);
+    return slab_rows_for(cdiv((long)g->B * g->Hout * g->Wout, conv_gemm_bm(dtype, g)));
 }
 
 extern "C" int nvae_conv_gemm(int dtype, const NvaeConvGeom* g, const void* src, const void* wT, int w_ld,

@@ -449,7 +449,7 @@ __global__ __launch_bounds__(512) void k_wgrad_halo(NvaeConvGeom g, const T* __r
 }
 
 static bool wgrad_halo_ok(int dtype, const NvaeConvGeom* g, const float* db) {
-    return is16(dtype) && db == nullptr && g->KH == g->KW && (g->KH == 5 || g->KH == 3) && g->stride == 1 &&
+    return !g_nvae_det && is16(dtype) && db == nullptr && g->KH == g->KW && (g->KH == 5 || g->KH == 3) && g->stride == 1 &&
            g->div == 1 && g->pad_t == (g->KH - 1) / 2 && g->pad_l == (g->KW - 1) / 2 && g->Hin == g->Hout &&
            g->Win == g->Wout && g->Hin % 8 == 0 && g->Win % 16 == 0 && g->Cin % 64 == 0 && g->Cout % 192 == 0 &&
            (long)g->B * g->Hin * g->Win >= 16384;
@@ -512,10 +512,10 @@ static WgradPlan plan_conv_wgrad(const NvaeConvGeom* g, long scratch_floats, int
     settle(nsplit);
     // > 4 splits are combined through a slab (same-address f32 atomics serialise, ~0.3 us each);
     // without enough scratch fall back to 4 atomically combined splits
-    p.slab = p.nsplit > 4;
+    p.slab = p.nsplit > (g_nvae_det ? 1 : 4);
     if (p.slab && scratch_floats < (long)p.nsplit * (K + 1) * N) {
         p.slab = false;
-        settle(4);
+        settle(g_nvae_det ? 1 : 4);          // (deterministic: atomically combined splits are not an option)
     }
     return p;
 }

@@ -229,7 +229,7 @@ __global__ __launch_bounds__(256, 2) void k_dw5_fwd_ring(const T* __restrict__ x
     dw_f2 wr[25];
 #pragma unroll
     for (int t = 0; t < 25; ++t) {
-        const int tap = flip ? 24 - t : t;
+        const int tap = (flip & 1) ? 24 - t : t;
         const float2 u = cval ? *(const float2*)(w + (long)tap * C + c) : make_float2(0.f, 0.f);
         wr[t].x = u.x; wr[t].y = u.y;
     }
@@ -354,7 +354,7 @@ __global__ __launch_bounds__(256, 2) void k_dw5_fwd_ring(const T* __restrict__ x
 #pragma unroll
                 for (int wv = 0; wv < 4; ++wv) { a1 += red[(wv * 32 + pr) * 4 + e]; a2 += red[(wv * 32 + pr) * 4 + 2 + e]; }
                 // workgroup y adds into row y % rows of the zeroed slab (<= 64 adders per address, conv_gemm.hip)
-                const int row = blockIdx.y % cdiv_dev((int)gridDim.y, 64);
+                const int row = (flip & 2) ? (int)blockIdx.y : blockIdx.y % cdiv_dev((int)gridDim.y, 64);   // bit 1: one row per workgroup
                 atomicAdd(stats + ((long)row * 2) * C + cc, a1);
                 atomicAdd(stats + ((long)row * 2 + 1) * C + cc, a2);
             }
@@ -374,7 +374,7 @@ static long dw_ring_rows(int B, int H, int W, int C) {
 
 extern "C" int nvae_dwconv5_stats_rows(int dtype, int B, int H, int W, int C) {
     if (!is16(dtype) || B <= 0 || H <= 0 || W <= 0 || C < 8 || C % 8) return 0;
-    return cdiv(dw_ring_rows(B, H, W, C), 64);
+    return slab_rows_for(dw_ring_rows(B, H, W, C));
 }
 
 static int dw_pre_from(const char* who, const NvaeBnIn* in, int act, long rows, DwPre& pre) {
@@ -406,9 +406,9 @@ static int dwconv5_impl(int dtype, const void* x, const float* w, const float* b
         dim3 grid(strips, (unsigned)dw_ring_rows(B, H, W, C));
 #define DW_RING(T_)                                                                                              \
         if (small)                                                                                               \
-            hipLaunchKernelGGL((k_dw5_fwd_ring<T_, 4, 4, 4>), grid, 256, 0, (hipStream_t)stream, (const T_*)x, w, bias, (T_*)y, B, H, W, C, tx, tx * ty, flip, accumulate, zero_page(), stats, pre); \
+            hipLaunchKernelGGL((k_dw5_fwd_ring<T_, 4, 4, 4>), grid, 256, 0, (hipStream_t)stream, (const T_*)x, w, bias, (T_*)y, B, H, W, C, tx, tx * ty, flip | (g_nvae_det ? 2 : 0), accumulate, zero_page(), stats, pre); \
         else                                                                                                     \
-            hipLaunchKernelGGL((k_dw5_fwd_ring<T_, 8, 8, 1>), grid, 256, 0, (hipStream_t)stream, (const T_*)x, w, bias, (T_*)y, B, H, W, C, tx, tx * ty, flip, accumulate, zero_page(), stats, pre);
+            hipLaunchKernelGGL((k_dw5_fwd_ring<T_, 8, 8, 1>), grid, 256, 0, (hipStream_t)stream, (const T_*)x, w, bias, (T_*)y, B, H, W, C, tx, tx * ty, flip | (g_nvae_det ? 2 : 0), accumulate, zero_page(), stats, pre);
         if (dtype == NVAE_BF16) { DW_RING(bf16) } else { DW_RING(f16) }
 #undef DW_RING
         NVAE_LAUNCH_CHECK("dwconv5");
@@ -703,7 +703,7 @@ static int dwconv5_wgrad_impl(int dtype, const void* x, const void* dy, float* d
     if (want > 1024 / strips) want = 1024 / strips;
     if (want < cdiv(256, strips)) want = cdiv(256, strips);
     if (want > units) want = units;
-    if (want < 1) want = 1;
+    if (want < 1 || g_nvae_det) want = 1;          // deterministic: one workgroup (one adder) per channel strip
     long upb = (units + want - 1) / want;
     const long chunks = (units + upb - 1) / upb;
     NVAE_REQUIRE(chunks <= 65535, "dwconv5_wgrad: too many tiles");
@@ -722,7 +722,7 @@ static int dwconv5_wgrad_impl(int dtype, const void* x, const void* dy, float* d
         if (w4 > 1024 / strips) w4 = 1024 / strips;
         if (w4 < cdiv(256, strips)) w4 = cdiv(256, strips);
         if (w4 > u4) w4 = u4;
-        if (w4 < 1) w4 = 1;
+        if (w4 < 1 || g_nvae_det) w4 = 1;
         if (dtype == NVAE_BF16)
             hipLaunchKernelGGL((k_dw5_wgrad_ring<bf16, 4, 4, 4>), dim3(strips, (unsigned)w4), 256, 0, (hipStream_t)stream, (const bf16*)x, (const bf16*)dy, dw, db, B, H, W, C, 1, 1, zero_page(), pre);
         else

@@ -5,6 +5,9 @@
 
 thread_local char g_nvae_err[512] = {0};
 extern "C" const char* nvae_last_error(void) { return g_nvae_err; }
+int g_nvae_det = 0;
+extern "C" int nvae_set_deterministic(int on) { g_nvae_det = on != 0; return NVAE_OK; }
+extern "C" int nvae_get_deterministic(void) { return g_nvae_det; }
 extern "C" int nvae_abi_version(void) { return NVAE_ABI_VERSION; }
 
 static inline int ew_grid(long n8) {

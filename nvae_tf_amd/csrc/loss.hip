@@ -283,9 +283,45 @@ __global__ void k_bn_absmax_fwd(const float* __restrict__ params, const int* __r
     }
 }
 
+// deterministic twin: one workgroup, the layers' maxima are summed by one thread in layer order
+__global__ void k_bn_absmax_fwd_ordered(const float* __restrict__ params, const int* __restrict__ table,
+                                        int n_layers, float lambda, float* bn_loss, int* __restrict__ argmax) {
+    __shared__ float s_best[4];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float total = 0.f;
+    for (int l0 = 0; l0 < n_layers; l0 += 4) {
+        const int layer = l0 + wave;
+        float best = -1.f;
+        int bi = 0;
+        if (layer < n_layers) {
+            const int off = table[2 * layer], C = table[2 * layer + 1];
+            for (int c = lane; c < C; c += 64) {
+                const float v = fabsf(params[off + c]);
+                if (v > best) { best = v; bi = c; }
+            }
+            for (int o = 32; o > 0; o >>= 1) {
+                const float ob = __shfl_xor(best, o, 64);
+                const int oi = __shfl_xor(bi, o, 64);
+                if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+            }
+            if (lane == 0) argmax[layer] = bi;
+        }
+        if (lane == 0) s_best[wave] = layer < n_layers ? lambda * best : 0.f;
+        __syncthreads();
+        if (threadIdx.x == 0) total += ((s_best[0] + s_best[1]) + s_best[2]) + s_best[3];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *bn_loss += total;
+}
+
 extern "C" int nvae_bn_absmax_fwd(const float* params, const int* table, int n_layers, float lambda,
                                   float* bn_loss, int* argmax, void* stream) {
     NVAE_REQUIRE(n_layers > 0 && params && table && bn_loss && argmax, "bn_absmax_fwd: bad args");
+    if (g_nvae_det) {
+        hipLaunchKernelGGL(k_bn_absmax_fwd_ordered, 1, 256, 0, (hipStream_t)stream, params, table, n_layers, lambda, bn_loss, argmax);
+        NVAE_LAUNCH_CHECK("bn_absmax_fwd (ordered)");
+        return NVAE_OK;
+    }
     hipLaunchKernelGGL(k_bn_absmax_fwd, cdiv(n_layers, 4), 256, 0, (hipStream_t)stream, params, table, n_layers, lambda, bn_loss, argmax);
     NVAE_LAUNCH_CHECK("bn_absmax_fwd");
     return NVAE_OK;

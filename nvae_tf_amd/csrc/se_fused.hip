@@ -584,7 +584,7 @@ static int sef_split(int B, int HW, int C) {
 extern "C" int nvae_se_fused_rows(int B, int HW, int C) {
     if (B <= 0) return 0;
     const int S = sef_split(B, HW, C);
-    return cdiv(S > 1 ? B * S : sef_wgs(B), 64);
+    return slab_rows_for(S > 1 ? B * S : sef_wgs(B));
 }
 
 static int sef_check(const char* who, int B, int HW, int C, int Hd) {
@@ -619,7 +619,7 @@ extern "C" int nvae_se_fused_fwd(int dtype, const void* x, const NvaeBnIn* bn_in
     const int RL = 256 / (C / 8);
     const int S = sef_split(B, HW, C);
     if (S > 1) {
-        SefOut so{(void*)stats, cdiv(B * S, 64)};
+        SefOut so{(void*)stats, slab_rows_for(B * S)};
         SefSplit sp{S, g_se_ws, g_se_ws + (size_t)B * S * C, g_se_counters};
         const int P = HW / S;
         const int nch = (P % RL == 0) ? P / RL : 0;
@@ -633,7 +633,7 @@ extern "C" int nvae_se_fused_fwd(int dtype, const void* x, const NvaeBnIn* bn_in
         return NVAE_OK;
     }
     const int imgs = sef_imgs(B), wgs = sef_wgs(B);
-    SefOut so{(void*)stats, cdiv(wgs, 64)};
+    SefOut so{(void*)stats, slab_rows_for(wgs)};
     const int nch = (HW % RL == 0) ? HW / RL : 0;
 #define SEF_LAUNCH(N_)                                                                                              \
     DISPATCH_T(dtype, hipLaunchKernelGGL((k_se_fused_fwd<T, N_>), wgs, 256, 0, (hipStream_t)stream, (const T*)x, bn, \
@@ -816,7 +816,7 @@ extern "C" int nvae_se_fused_bwd(int dtype, const void* x, const float* bn_scale
     const int RL = 256 / (C / 8);
     const int S = sef_split(B, HW, C);
     if (S > 1) {
-        SefOut so{(void*)partials, cdiv(B * S, 64)};
+        SefOut so{(void*)partials, slab_rows_for(B * S)};
         SefSplit sp{S, g_se_ws, g_se_ws + (size_t)B * S * C, g_se_counters};
         const int P = HW / S;
         const int nch = (P % RL == 0) ? P / RL : 0;
@@ -830,7 +830,7 @@ extern "C" int nvae_se_fused_bwd(int dtype, const void* x, const float* bn_scale
         return NVAE_OK;
     }
     const int imgs = sef_imgs(B), wgs = sef_wgs(B);
-    SefOut so{(void*)partials, cdiv(wgs, 64)};
+    SefOut so{(void*)partials, slab_rows_for(wgs)};
     const int nch = (HW % RL == 0) ? HW / RL : 0;
 #define SEF_LAUNCH(N_)                                                                                                \
     DISPATCH_T(dtype, hipLaunchKernelGGL((k_se_fused_bwd<T, N_>), wgs, 256, 0, (hipStream_t)stream, (const T*)x, bn_scale, \

@@ -116,7 +116,8 @@ class NVAE:
         ps.prep_marks = cmarks
         self.n_groups = self.decoder.n_groups
         # per-image activation footprint decides the scratch pool; generous fixed size
-        ps.finalize(self.device, dtype, zero_pool_floats=1 << 24)
+        # (deterministic mode: one statistics-slab row per producing workgroup instead of one per 64)
+        ps.finalize(self.device, dtype, zero_pool_floats=(1 << 27) if L.load().nvae_get_deterministic() else (1 << 24))
 
         self.epoch = 0          # updated at the start of each epoch (models.py:82-83)
         self.steps = 0          # updated for each training step (models.py:86-87)

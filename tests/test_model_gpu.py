@@ -8,6 +8,7 @@ the gradient scale per tensor; bf16 path 3e-2 on losses, 0.2 of the gradient sca
 exempt; bf16 keeps 8 significant bits through ~60 layers), gradient cosine > 0.9993; f16 path 5e-3 on losses, 0.1 per
 tensor (measured: median 3.5e-3, worst 5.6e-2), cosine > 0.9999."""
 import math
+import os
 
 import pytest
 import torch
@@ -254,6 +255,97 @@ def test_checkpoint_resume_continues_exactly(lib, dev, tmp_path):
     _params_close(a.ps.params, b.ps.params)
     _state_close(a.ps.state, b.ps.state)
     _params_close(a.ps.adam_u, b.ps.adam_u)
+
+
+@pytest.fixture
+def deterministic(lib):
+    """NVAE_DETERMINISTIC=1 for one test (nvae_set_deterministic: must be on before any model of the test is built)."""
+    lib.nvae_set_deterministic(1)
+    yield
+    lib.nvae_set_deterministic(0)
+
+
+def _bits_equal(a, b):
+    assert torch.equal(a.ps.params, b.ps.params) and torch.equal(a.ps.state, b.ps.state)
+    assert torch.equal(a.ps.adam_m, b.ps.adam_m) and torch.equal(a.ps.adam_u, b.ps.adam_u)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16], ids=["f32", "bf16", "f16"])
+def test_deterministic_mode_is_bit_reproducible(lib, dev, dtype, deterministic, tmp_path):
+    """NVAE_DETERMINISTIC: every sum across workgroups has one adder per address or a fixed order (one
+    statistics-slab row per producing workgroup, slab-combined or unsplit weight gradients, ordered regulariser sum).
+    (a) two models from the same state run the same graphed steps -> every parameter, BatchNorm / spectral-norm state and
+    Adamax slot equal BIT FOR BIT, also against eager steps; (b) train -> checkpoint -> load into a scrambled model ->
+    capture -> train equals the uninterrupted run with torch.equal (the default mode meets it to the Adamax-noise
+    tolerance only: test_checkpoint_resume_continues_exactly); (c) the gradients agree with the default mode's to rounding."""
+    from nvae_tf_amd.train import load_checkpoint, save_checkpoint
+    assert lib.nvae_get_deterministic() == 1
+    _, a, x, _ = build_pair(dev, dtype)
+    _, b, _, _ = build_pair(dev, dtype)
+    _, c, _, _ = build_pair(dev, dtype)
+    xs = x.to(dtype)
+    for m in (a, b, c):
+        m.steps = 40
+    a.capture_train_step(xs.shape)
+    b.capture_train_step(xs.shape)
+    losses = [[], [], []]
+    for _ in range(3):
+        losses[0].append(float(a.train_step_graphed(xs)["loss"]))
+        losses[1].append(float(b.train_step_graphed(xs)["loss"]))
+        losses[2].append(float(c.train_step(xs)["loss"]))            # eager: same launches, other timing
+    torch.cuda.synchronize()
+    assert losses[0] == losses[1] == losses[2], losses
+    _bits_equal(a, b)
+    _bits_equal(a, c)
+    # (b) exact resume
+    path = str(tmp_path / "ck" / "epoch_1.pt")
+    save_checkpoint(a, path, epoch=1)
+    for _ in range(2):
+        out_a = a.train_step_graphed(xs)
+    _, d, _, _ = build_pair(dev, dtype)
+    for _ in range(2):
+        d.train_step(xs)                          # scramble d's state, counters and RNG
+    assert load_checkpoint(d, path) == 1
+    d.capture_train_step(xs.shape)
+    for _ in range(2):
+        out_d = d.train_step_graphed(xs)
+    torch.cuda.synchronize()
+    assert float(out_a["loss"]) == float(out_d["loss"])
+    _bits_equal(a, d)
+    # (c) against the default mode: same arithmetic, other summation orders
+    lib.nvae_set_deterministic(0)
+    _, e, _, _ = build_pair(dev, dtype)
+    e.steps = 40
+    e.train_step(xs)
+    lib.nvae_set_deterministic(1)
+    _, f, _, _ = build_pair(dev, dtype)
+    f.steps = 40
+    f.train_step(xs)
+    torch.cuda.synchronize()
+    ge, gf = e.ps.grads.double(), f.ps.grads.double()
+    cos = float((ge * gf).sum() / (ge.norm() * gf.norm()))
+    assert cos > (0.999999 if dtype == torch.float32 else 0.999), cos
+
+
+def test_deterministic_mode_c2_architecture(lib, dev, deterministic):
+    """The benchmarked model (C2, batch 128, bf16) in deterministic mode: the halo / whole-image / image-split kernels, the
+    batched weight gradients and the side stream are all in play; two runs of three graph-replayed steps are bit-equal."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    x = bench.synthetic_batch(128, 1, dev).to(torch.bfloat16)
+    runs = []
+    for _ in range(2):
+        m = bench.make_model(dev, torch.bfloat16, 128)
+        m.capture_train_step(x.shape, warmup=1)
+        m._static_x.copy_(x)
+        ls = [float(m.train_step_graphed(None)["loss"]) for _ in range(3)]
+        torch.cuda.synchronize()
+        runs.append((ls, m.ps.params.clone(), m.ps.adam_u.clone(), m.ps.state.clone()))
+        del m
+    assert runs[0][0] == runs[1][0], (runs[0][0], runs[1][0])
+    for i in (1, 2, 3):
+        assert torch.equal(runs[0][i], runs[1][i])
 
 
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-3), (torch.bfloat16, 2e-2), (torch.float16, 3e-3)],
