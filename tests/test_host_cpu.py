@@ -34,6 +34,27 @@ def test_stale_library_is_refused(monkeypatch):
         _lib.load()
 
 
+def test_deterministic_switch_and_slab_rows(lib, monkeypatch):
+    """NVAE_DETERMINISTIC=1 is read when the library is loaded; with it the slab-row queries return one row per producing
+    workgroup instead of one per 64 (host logic only: no kernel runs)."""
+    import ctypes as C
+    from nvae_tf_amd import _lib
+    g = _lib.ConvGeom(128, 32, 32, 32, 32, 32, 192, 1, 1, 1, 0, 0, 1, 0, 32, 192, 192)     # 512 M-tiles of 256 rows
+    try:
+        assert lib.nvae_get_deterministic() == 0
+        r0 = lib.nvae_conv_gemm_stats_rows(_lib.BF16, C.byref(g))
+        s0 = lib.nvae_se_fused_rows(128, 16, 256)
+        monkeypatch.setattr(_lib, "_lib", None)
+        monkeypatch.setenv("NVAE_DETERMINISTIC", "1")
+        lib2 = _lib.load()
+        assert lib2.nvae_get_deterministic() == 1
+        r1 = lib2.nvae_conv_gemm_stats_rows(_lib.BF16, C.byref(g))
+        s1 = lib2.nvae_se_fused_rows(128, 16, 256)
+        assert r0 == 8 and r1 == 512 and s1 > s0 >= 1
+    finally:
+        lib.nvae_set_deterministic(0)
+
+
 def make(groups, cells, dtype=torch.bfloat16, **kw):
     from nvae_tf_amd.models import NVAE
     return NVAE(32, 32, cells, 2, 3, 20, len(groups), groups, 2, 3, 0.01, 2, 400, 1000, True, [1, 32, 32, 1],
