@@ -501,7 +501,8 @@ def main():
                                    "2 cells/group, 20 latents/group; full train step "
                                    "(SN + fwd + ELBO + bwd + Adamax)",
                        "global_batch": args.batch * world, "batch_per_gpu": args.batch,
-                       "parallelism": f"dp{world}", "hip_graph": use_graph},
+                       "parallelism": f"dp{world}", "hip_graph": use_graph,
+                       "deterministic": bool(__import__("nvae_tf_amd._lib", fromlist=["load"]).load().nvae_get_deterministic())},
             "loss_nats": loss,
             "fwd_mac_per_image": macs,      # counted from this run's launches; SURVEY 8d: 6 949.4 M (dense + depthwise)
             "e2e_mfma_frac": value / world * TRAIN_FLOP_PER_IMG / 1e12 / peak_tf,
