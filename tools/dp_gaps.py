@@ -9,7 +9,7 @@ for r in csv.DictReader(open(f)):
     rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
 rows.sort()
 import re
-is_ccl = lambda n: re.search(r"nccl|rccl", n, re.I) is not None and "rocclr" not in n
+is_ccl = lambda n: re.search(r"nccl|rccl|oneRankReduce", n, re.I) is not None and "rocclr" not in n
 adamax = [i for i, r in enumerate(rows) if "k_adamax" in r[2]]
 print(f"{len(rows)} kernels, {len(adamax)} optimizer steps, {sum(is_ccl(r[2]) for r in rows)} RCCL kernels")
 # per step (adamax end to adamax end): wall time, time with NO kernel running on any stream, kernels
@@ -22,9 +22,10 @@ for a, b in zip(adamax[:-1], adamax[1:]):
             idle += (s_ - busy_end) / 1e3
             gaps.append(((s_ - busy_end) / 1e3, rows[i - 1][2][:48], n_[:48]))
         busy_end = max(busy_end, e_)
-    steps.append(((rows[b][1] - rows[a][1]) / 1e3, idle, b - a, sum(is_ccl(rows[i][2]) for i in range(a + 1, b + 1)), sorted(gaps, reverse=True)[:6]))
-for i, (wall, idle, n, nccl, gaps) in enumerate(steps):
-    print(f"step {i:2d}: wall {wall:9.1f} us  chip idle {idle:8.1f} us  kernels {n:5d}  rccl kernels {nccl}")
+    ccl = [(rows[i][1] - rows[i][0]) / 1e3 for i in range(a + 1, b + 1) if is_ccl(rows[i][2])]
+    steps.append(((rows[b][1] - rows[a][1]) / 1e3, idle, b - a, len(ccl), sorted(gaps, reverse=True)[:6], sum(ccl)))
+for i, (wall, idle, n, nccl, gaps, ccl_us) in enumerate(steps):
+    print(f"step {i:2d}: wall {wall:9.1f} us  chip idle {idle:8.1f} us  kernels {n:5d}  rccl kernels {nccl} ({ccl_us:7.1f} us)")
 for i in (len(steps) // 4, 3 * len(steps) // 4):
     print(f"--- largest idle gaps of step {i}:")
     for g in steps[i][4]:
