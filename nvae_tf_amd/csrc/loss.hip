@@ -2,6 +2,7 @@
 // reconstruction, KL balancing / loss assembly, BN-gamma abs-max regulariser.
 // All reductions are f32: wave64 shuffle reduction, then one LDS hop per block.
 #include "common.h"
+#include "bn_fin.h"
 
 __device__ __forceinline__ float softclamp5_(float x) { return 5.0f * tanhf(x * 0.2f); }
 __device__ __forceinline__ float dsoftclamp5_(float x) {
@@ -10,17 +11,23 @@ __device__ __forceinline__ float dsoftclamp5_(float x) {
 }
 #define HALF_LOG_2PI 0.9189385332046727f
 
-// One block per image.  common.py:76-102 + models.py:197-201 + util.py:39-46.
+// One block per image, or S blocks per image with an ordered last-arriver sum when the batch alone leaves most of the chip idle
+// (C5: 32 images x 20 480 latent elements ran 35 us on 32 CUs).  common.py:76-102 + models.py:197-201 + util.py:39-46.
+#define SAMP_MAX_B 4096
+#define SAMP_MAX_S 16
+static __device__ float g_samp_part[SAMP_MAX_B * SAMP_MAX_S * 3];    // (one launch at a time per device: stream-ordered use)
+static __device__ int g_samp_count[SAMP_MAX_B];                       // zero at rest
 template <typename T>
 __global__ void k_sampler_fwd(const float* __restrict__ enc_p, const float* __restrict__ dec_p,
                               const float* __restrict__ eps, T* __restrict__ z, float* __restrict__ kl,
                               float* logq, float* logp, float* __restrict__ mu_sigma, int HW, int L,
                               long total) {
     __shared__ float sm[4];
-    const int b = blockIdx.x;
+    const int b = blockIdx.y;
+    const int S = gridDim.x, sl = blockIdx.x;       // S workgroups per image (large latent maps at small batch: C4 / C5)
     const int n = HW * L;
     float akl = 0.f, aq = 0.f, ap = 0.f;
-    for (int e = threadIdx.x; e < n; e += 256) {
+    for (int e = sl * 256 + threadIdx.x; e < n; e += S * 256) {
         int pix = e / L, l = e - pix * L;
         long pbase = ((long)b * HW + pix) * (2 * L) + l;
         long idx = (long)b * n + e;
@@ -54,11 +61,29 @@ __global__ void k_sampler_fwd(const float* __restrict__ enc_p, const float* __re
         }
     }
     akl = block_sum256(akl, sm);
-    if (threadIdx.x == 0) kl[b] = akl;
     if (logq) {
         aq = block_sum256(aq, sm);
         ap = block_sum256(ap, sm);
-        if (threadIdx.x == 0) { logq[b] += aq; logp[b] += ap; }
+    }
+    if (S == 1) {
+        if (threadIdx.x == 0) {
+            kl[b] = akl;
+            if (logq) { logq[b] += aq; logp[b] += ap; }
+        }
+        return;
+    }
+    // partial sums out, the image's last arriver adds them in slice order (independent of the arrival order)
+    float* part = g_samp_part + ((long)b * SAMP_MAX_S + sl) * 3;
+    if (threadIdx.x == 0) { bn_store_partial(part, akl); bn_store_partial(part + 1, aq); bn_store_partial(part + 2, ap); }
+    if (!bn_last_arriver(g_samp_count + b, S)) return;
+    if (threadIdx.x == 0) {
+        float t0 = 0.f, t1 = 0.f, t2 = 0.f;
+        for (int q = 0; q < S; ++q) {
+            const float* pq = g_samp_part + ((long)b * SAMP_MAX_S + q) * 3;
+            t0 += bn_load_partial(pq); t1 += bn_load_partial(pq + 1); t2 += bn_load_partial(pq + 2);
+        }
+        kl[b] = t0;
+        if (logq) { logq[b] += t1; logp[b] += t2; }
     }
 }
 
@@ -67,7 +92,9 @@ extern "C" int nvae_sampler_fwd(int dtype, const float* enc_p, const float* dec_
                                 int HW, int L, void* stream) {
     NVAE_REQUIRE(B > 0 && HW > 0 && L > 0 && enc_p && eps && z && kl, "sampler_fwd: bad args");
     NVAE_REQUIRE((logq == nullptr) == (logp == nullptr), "sampler_fwd: logq/logp must both be set or NULL");
-    DISPATCH_T(dtype, hipLaunchKernelGGL((k_sampler_fwd<T>), B, 256, 0, (hipStream_t)stream, enc_p, dec_p, eps, (T*)z, kl, logq, logp, mu_sigma, HW, L, (long)B * HW * L);)
+    int S = 1;
+    if (B <= SAMP_MAX_B) while (S < SAMP_MAX_S && (long)B * S < 512 && (long)HW * L / (2 * S) >= 1024) S *= 2;
+    DISPATCH_T(dtype, hipLaunchKernelGGL((k_sampler_fwd<T>), dim3(S, B), 256, 0, (hipStream_t)stream, enc_p, dec_p, eps, (T*)z, kl, logq, logp, mu_sigma, HW, L, (long)B * HW * L);)
     NVAE_LAUNCH_CHECK("sampler_fwd");
     return NVAE_OK;
 }
