@@ -639,7 +639,7 @@ extern "C" int nvae_se_fused_fwd(int dtype, const void* x, const NvaeBnIn* bn_in
     DISPATCH_T(dtype, hipLaunchKernelGGL((k_se_fused_fwd<T, N_>), wgs, 256, 0, (hipStream_t)stream, (const T*)x, bn, \
                                          (const T*)skip, (T*)y, B, HW, C, Hd, imgs, w1, b1, w2, b2, skip_scale,      \
                                          branch_scale, pooled_sum, gate, hidden, so);)
-    if (nch == 1) SEF_LAUNCH(1) else if (nch == 2) SEF_LAUNCH(2) else if (nch == 4) SEF_LAUNCH(4) else SEF_LAUNCH(0)
+    if (nch == 1) SEF_LAUNCH(1) else if (nch == 2) SEF_LAUNCH(2) else if (nch == 4) SEF_LAUNCH(4) else if (nch == 8) SEF_LAUNCH(8) else SEF_LAUNCH(0)
 #undef SEF_LAUNCH
     NVAE_LAUNCH_CHECK("se_fused_fwd");
     return NVAE_OK;
@@ -836,7 +836,7 @@ extern "C" int nvae_se_fused_bwd(int dtype, const void* x, const float* bn_scale
     DISPATCH_T(dtype, hipLaunchKernelGGL((k_se_fused_bwd<T, N_>), wgs, 256, 0, (hipStream_t)stream, (const T*)x, bn_scale, \
                                          bn_shift, act, (const T*)dy, gate, hidden, (T*)dx, (T*)dskip, B, HW, C, Hd, imgs,  \
                                          w1, w2, skip_scale, branch_scale, acc_dx, dskip ? acc_dskip : 0, scratch, so);)
-    if (nch == 1) SEF_LAUNCH(1) else if (nch == 2) SEF_LAUNCH(2) else if (nch == 4) SEF_LAUNCH(4) else SEF_LAUNCH(0)
+    if (nch == 1) SEF_LAUNCH(1) else if (nch == 2) SEF_LAUNCH(2) else if (nch == 4) SEF_LAUNCH(4) else if (nch == 8) SEF_LAUNCH(8) else SEF_LAUNCH(0)
 #undef SEF_LAUNCH
     NVAE_LAUNCH_CHECK("se_fused_bwd");
     return NVAE_OK;

@@ -587,7 +587,8 @@ def test_fused_bn_se_chain(lib, dev, dtype, shape, lazy, se_path, monkeypatch, r
 
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16", "f16"])
-@pytest.mark.parametrize("shape,ss,bs", [((3, 8, 8, 128), 0.1, 1.0), ((4, 4, 4, 256), 1.0, 0.1), ((2, 32, 32, 32), 1.0, 0.1)])
+@pytest.mark.parametrize("shape,ss,bs", [((3, 8, 8, 128), 0.1, 1.0), ((4, 4, 4, 256), 1.0, 0.1), ((2, 32, 32, 32), 1.0, 0.1),
+                                          ((3, 16, 16, 64), 1.0, 0.1)])      # (the last: 8 register-resident chunks per thread)
 @pytest.mark.parametrize("se_path", ["fused", "strips", "split2", "split8"])
 def test_se_residual(lib, dev, dtype, shape, ss, bs, se_path, monkeypatch, request):
     from nvae_tf_amd import ops
