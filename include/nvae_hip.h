@@ -227,6 +227,11 @@ int nvae_dwconv5_wgrad(int dtype, const void* x, const void* dy, float* dw, floa
  * nvae_se_fused_fwd); weight gradient: the final scale / shift table.                                        */
 int nvae_dwconv5_pre(int dtype, const void* x, const NvaeBnIn* bn, int act, const float* w, const float* bias,
                      void* y, int B, int H, int W, int C, float* stats /* NULL or output slab */, void* stream);
+/* Data gradient of the depthwise conv that also reduces the backward sums of the BatchNorm(+act) in front of the conv (x0 = that
+ * BatchNorm's input, scale / shift = its final coefficient table): partials[nvae_dwconv5_stats_rows(...)][2][C], zeroed by the
+ * caller, consumed by nvae_bn_bwd_apply_fin.  16-bit activation types only (decoder.py:128-131 backward). */
+int nvae_dwconv5_bnbwd(int dtype, const void* dy, const float* w, void* dx, int B, int H, int W, int C, const void* x0,
+                       const float* scale, const float* shift, int act, float* partials, void* stream);
 int nvae_dwconv5_wgrad_pre(int dtype, const void* x, const float* scale, const float* shift, int act,
                            const void* dy, float* dw, float* db, int B, int H, int W, int C, void* stream);
 

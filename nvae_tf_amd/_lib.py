@@ -87,6 +87,7 @@ _SIGS = {
     "nvae_dwconv5": [_i, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i],
     "nvae_dwconv5_wgrad": [_i, _p, _p, _p, _p, _i, _i, _i, _i],
     "nvae_dwconv5_pre": [_i, _p, _p, _i, _p, _p, _p, _i, _i, _i, _i, _p],
+    "nvae_dwconv5_bnbwd": [_i, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _i, _p],
     "nvae_dwconv5_wgrad_pre": [_i, _p, _p, _p, _i, _p, _p, _p, _i, _i, _i, _i],
     "nvae_dwconv5_stats": [_i, _p, _p, _p, _p, _i, _i, _i, _i, _p],
     "nvae_reduce_splits": None,

@@ -181,6 +181,10 @@ template <> __device__ __forceinline__ unsigned dw_pack<f16>(dw_f2 v) {
 // zero, because the padding applies to the activated tensor.  The whole image is one tile at 4x4 / 8x8, so every
 // element is transformed exactly once per pass.
 struct DwPre { BnFromSlab bn; int on; int act; };
+// Data-gradient launches whose output is d act(BN(x0)) for a BatchNorm this conv was the only consumer of: the kernel also
+// accumulates that BatchNorm's backward sums (sum dpre, sum dpre * x0 with dpre = dx * act'(scale * x0 + shift)) into the slab
+// `stats`, read by nvae_bn_bwd_apply_fin - the counterpart of the BN-backward epilogue of the implicit GEMM (conv_gemm.hip).
+struct DwBnBwd { const void* x0; const float* scale; const float* shift; int act; };
 template <typename T>
 __device__ __forceinline__ void dw_pre_coefs(const DwPre& pre, int C, int c_base, float (&sc)[8], float (&sh)[8]) {
     __shared__ float t_sc[DW_CC], t_sh[DW_CC];
@@ -212,7 +216,7 @@ __global__ __launch_bounds__(256, 2) void k_dw5_fwd_ring(const T* __restrict__ x
                                                       const float* __restrict__ bias, T* y, int B, int H,
                                                       int W, int C, int tiles_x, int tiles_per_img, int flip,
                                                       int acc, const uint4* __restrict__ zeros,
-                                                      float* __restrict__ stats, DwPre pre) {
+                                                      float* __restrict__ stats, DwPre pre, DwBnBwd bb) {
     static_assert(IMGS * (TH / 2) * (TW / 4) == 8, "8 pixel lanes of 2x4 outputs per workgroup");
     constexpr int NS = 2;
     constexpr int HTH = TH + 4, HTW = TW + 4, NCH = IMGS * HTH * HTW * 8;     // 16-B chunks per unit
@@ -236,6 +240,9 @@ __global__ __launch_bounds__(256, 2) void k_dw5_fwd_ring(const T* __restrict__ x
     dw_f2 bv;
     bv.x = (bias && !acc && cval) ? bias[c] : 0.f;
     bv.y = (bias && !acc && cval) ? bias[c + 1] : 0.f;
+    const T* bx0 = (const T*)bb.x0;
+    dw_f2 bsc = {0.f, 0.f}, bsh = {0.f, 0.f};
+    if (bx0 && cval) { bsc.x = bb.scale[c]; bsc.y = bb.scale[c + 1]; bsh.x = bb.shift[c]; bsh.y = bb.shift[c + 1]; }
     const long units = IMGS == 1 ? (long)B * tiles_per_img : (long)(B + IMGS - 1) / IMGS;
     const int nmine = blockIdx.y < units ? (int)((units - blockIdx.y + gridDim.y - 1) / gridDim.y) : 0;
     auto unit_of = [&](int i, long& b, int& ty, int& tx) {      // first image and tile of unit i
@@ -304,6 +311,17 @@ __global__ __launch_bounds__(256, 2) void k_dw5_fwd_ring(const T* __restrict__ x
                 if (acc && live && gy0 + r < H && gx0 + p < W)
                     o[r][p] = dw_unpack<T>(*(const unsigned*)(y + (((b * H + gy0 + r) * (long)W + gx0 + p) * C + c)));
             }
+        unsigned x0v[2][4];
+        if (bx0) {        // the BatchNorm input at this thread's outputs, requested before the tap loop
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    x0v[r][p] = 0u;
+                    if (live && gy0 + r < H && gx0 + p < W)
+                        x0v[r][p] = *(const unsigned*)(bx0 + (((b * H + gy0 + r) * (long)W + gx0 + p) * C + c));
+                }
+        }
 #pragma unroll
         for (int hr = 0; hr < 6; ++hr) {             // halo row rb*2 + hr feeds output rows hr-4 .. hr
             dw_f2 xr[8];
@@ -329,8 +347,19 @@ __global__ __launch_bounds__(256, 2) void k_dw5_fwd_ring(const T* __restrict__ x
                     if (gy0 + r < H && gx0 + p < W) {
                         *(unsigned*)(y + (((b * H + gy0 + r) * (long)W + gx0 + p) * C + c)) =
                             dw_pack<T>(o[r][p]);
-                        st1 += o[r][p];
-                        st2 += o[r][p] * o[r][p];
+                        if (bx0) {
+                            const dw_f2 xv = dw_unpack<T>(x0v[r][p]);
+                            dw_f2 dpre = o[r][p];
+                            if (bb.act == ACT_SWISH) {
+                                const dw_f2 pa = xv * bsc + bsh;
+                                dpre.x *= dswishf_(pa.x); dpre.y *= dswishf_(pa.y);
+                            }
+                            st1 += dpre;
+                            st2 += dpre * xv;
+                        } else {
+                            st1 += o[r][p];
+                            st2 += o[r][p] * o[r][p];
+                        }
                     }
         }
         mask_cur = mask_keep;
@@ -394,10 +423,12 @@ static int dw_pre_from(const char* who, const NvaeBnIn* in, int act, long rows, 
 }
 
 static int dwconv5_impl(int dtype, const void* x, const float* w, const float* bias, void* y, int B, int H, int W,
-                        int C, int flip, int accumulate, float* stats, void* stream, const DwPre& pre = DwPre{}) {
+                        int C, int flip, int accumulate, float* stats, void* stream, const DwPre& pre = DwPre{},
+                        const DwBnBwd& bb = DwBnBwd{}) {
     NVAE_REQUIRE(B > 0 && H > 0 && W > 0 && C >= 8 && C % 8 == 0, "dwconv5: bad shape");
     NVAE_REQUIRE(aligned16(x) && aligned16(y) && aligned16(w) && (!bias || aligned16(bias)), "dwconv5: alignment");
-    NVAE_REQUIRE(!stats || (is16(dtype) && !flip && !accumulate), "dwconv5: statistics only from the 16-bit forward");
+    NVAE_REQUIRE(!stats || (is16(dtype) && !accumulate && (!flip || bb.x0)), "dwconv5: statistics only from the 16-bit forward (or BatchNorm-backward sums from the data gradient)");
+    NVAE_REQUIRE(!bb.x0 || (stats && flip && is16(dtype)), "dwconv5_bnbwd: needs a slab, a data-gradient launch and a 16-bit activation type");
     const int strips = cdiv(C, DW_CC);
     NVAE_REQUIRE(B <= 65535, "dwconv5: batch too large for the grid");
     if (is16(dtype)) {
@@ -406,9 +437,9 @@ static int dwconv5_impl(int dtype, const void* x, const float* w, const float* b
         dim3 grid(strips, (unsigned)dw_ring_rows(B, H, W, C));
 #define DW_RING(T_)                                                                                              \
         if (small)                                                                                               \
-            hipLaunchKernelGGL((k_dw5_fwd_ring<T_, 4, 4, 4>), grid, 256, 0, (hipStream_t)stream, (const T_*)x, w, bias, (T_*)y, B, H, W, C, tx, tx * ty, flip | (g_nvae_det ? 2 : 0), accumulate, zero_page(), stats, pre); \
+            hipLaunchKernelGGL((k_dw5_fwd_ring<T_, 4, 4, 4>), grid, 256, 0, (hipStream_t)stream, (const T_*)x, w, bias, (T_*)y, B, H, W, C, tx, tx * ty, flip | (g_nvae_det ? 2 : 0), accumulate, zero_page(), stats, pre, bb); \
         else                                                                                                     \
-            hipLaunchKernelGGL((k_dw5_fwd_ring<T_, 8, 8, 1>), grid, 256, 0, (hipStream_t)stream, (const T_*)x, w, bias, (T_*)y, B, H, W, C, tx, tx * ty, flip | (g_nvae_det ? 2 : 0), accumulate, zero_page(), stats, pre);
+            hipLaunchKernelGGL((k_dw5_fwd_ring<T_, 8, 8, 1>), grid, 256, 0, (hipStream_t)stream, (const T_*)x, w, bias, (T_*)y, B, H, W, C, tx, tx * ty, flip | (g_nvae_det ? 2 : 0), accumulate, zero_page(), stats, pre, bb);
         if (dtype == NVAE_BF16) { DW_RING(bf16) } else { DW_RING(f16) }
 #undef DW_RING
         NVAE_LAUNCH_CHECK("dwconv5");
@@ -451,6 +482,18 @@ extern "C" int nvae_dwconv5_pre(int dtype, const void* x, const NvaeBnIn* bn, in
     DwPre pre;
     if (int e = dw_pre_from("dwconv5_pre", bn, act, (long)B * H * W, pre)) return e;
     return dwconv5_impl(dtype, x, w, bias, y, B, H, W, C, 0, 0, stats, stream, pre);
+}
+
+// Data gradient dx = dwconv5^T(dy) that also reduces the backward sums of the BatchNorm(+act) whose OUTPUT dx is the gradient of
+// (x0 = that BatchNorm's input, scale / shift = its final coefficients): partials[rows][2][C], rows =
+// nvae_dwconv5_stats_rows(...), zeroed by the caller, consumed by nvae_bn_bwd_apply_fin.  16-bit activation types.
+extern "C" int nvae_dwconv5_bnbwd(int dtype, const void* dy, const float* w, void* dx, int B, int H, int W, int C,
+                                  const void* x0, const float* scale, const float* shift, int act, float* partials,
+                                  void* stream) {
+    NVAE_REQUIRE(x0 && scale && shift && partials && aligned16(x0), "dwconv5_bnbwd: NULL / unaligned argument");
+    NVAE_REQUIRE(act == ACT_NONE || act == ACT_SWISH, "dwconv5_bnbwd: act %d unsupported", act);
+    DwBnBwd bb{x0, scale, shift, act};
+    return dwconv5_impl(dtype, dy, w, nullptr, dx, B, H, W, C, 1, 0, partials, stream, DwPre{}, bb);
 }
 
 // dw[kh,kw,c] += sum_{b,h,w} x[b,h+kh-2,w+kw-2,c] * dy[b,h,w,c];  db[c] += sum dy.

@@ -76,6 +76,7 @@ STATS_FIN = os.environ.get("NVAE_STATS_FIN", "0") != "0"
 FUSE_BN_BWD = os.environ.get("NVAE_BN_BWD_FUSE", "1") != "0"   # BN backward sums in the dgrad epilogue
 WGRAD_ORDER = os.environ.get("NVAE_WGRAD_ORDER", "queue")     # queue | small_first | big_first (within one flush)
 DW_PRE = os.environ.get("NVAE_DW_PRE", "1") != "0"           # BN(+Swish) in front of a depthwise conv applied in its LDS tile
+DW_BNBWD = os.environ.get("NVAE_DW_BNBWD", "1") != "0"       # ... and that BatchNorm's backward sums in the data-gradient kernel
 BN_BWD_SPLIT = os.environ.get("NVAE_BN_BWD_SPLIT", "0") != "0"  # unfused BN backward: reduce + self-finishing apply
 
 
@@ -638,7 +639,19 @@ def dwconv5(ctx: Ctx, x: Var, dw, want_stats: bool = False) -> Var:
                 ctx.side_launch(lambda: call("nvae_dwconv5_wgrad", ctx.dt, ptr(xt), ptr(y.g), ptr(ps.grads) + dw.w.off * 4,
                                              ptr(ps.grads) + dw.b.off * 4, B, H, W, Cc), y.g)
             g, acc = ctx.grad_of(x, y.gid)
-            call("nvae_dwconv5", ctx.dt, ptr(y.g), ptr(ps.view(dw.w)), None, ptr(g), B, H, W, Cc, 1, acc)
+            src = x.bn_src
+            if (FUSE_BN_BWD and DW_BNBWD and APPLY_FIN and src is not None and x.uses == 1 and not acc
+                    and ctx.dtype != torch.float32):
+                # x = act(BN(x0)) and this conv is its only consumer: the data-gradient kernel also reduces the BatchNorm's
+                # backward sums (as the implicit GEMM does in its epilogue); the BN closure then only applies
+                rows_b = L.load().nvae_dwconv5_stats_rows(ctx.dt, B, H, W, Cc)
+                src["partials"] = ctx.zero_slab(rows_b, Cc)
+                src["mtiles"] = rows_b
+                call("nvae_dwconv5_bnbwd", ctx.dt, ptr(y.g), ptr(ps.view(dw.w)), ptr(g), B, H, W, Cc, ptr(src["x"]),
+                     src["scale"], src["shift"], src["act"], ptr(src["partials"]))
+                src["fused"] = True
+            else:
+                call("nvae_dwconv5", ctx.dt, ptr(y.g), ptr(ps.view(dw.w)), None, ptr(g), B, H, W, Cc, 1, acc)
         ctx.tape.append(bwd)
     return y
 

@@ -683,16 +683,21 @@ def test_dwconv5(lib, dev, dtype, B, H, W_, C_):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
+@pytest.mark.parametrize("bnbwd", [False, True], ids=["bn-bwd-unfused", "bn-bwd-in-dgrad"])
 @pytest.mark.parametrize("B,H,C_,act", [(5, 4, 1536, 1), (3, 8, 96, 1), (2, 16, 192, 0), (40, 32, 64, 1)],
                          ids=["4x4", "8x8", "16x16", "many-tiles"])
-def test_dwconv5_bn_prologue(lib, dev, monkeypatch, dtype, B, H, C_, act):
+def test_dwconv5_bn_prologue(lib, dev, monkeypatch, dtype, B, H, C_, act, bnbwd):
     """BatchNorm(+Swish) -> depthwise 5x5 (decoder.py:125-131) with the BatchNorm applied inside the depthwise kernels
     (nvae_dwconv5_pre / nvae_dwconv5_wgrad_pre: never materialised) against the same chain with a materialised
     BatchNorm output: same rounding points, so outputs, statistics, every gradient and the published coefficient table /
-    moving statistics agree to f32 summation-order noise; and against the fp64 chain within the dtype's tolerance."""
+    moving statistics agree to f32 summation-order noise; and against the fp64 chain within the dtype's tolerance.
+    bn-bwd-in-dgrad (round 3, nvae_dwconv5_bnbwd): the depthwise data-gradient kernel also reduces the BatchNorm's backward
+    sums - from its f32 accumulators, where the unfused reduce reads the 16-bit-rounded gradient - so the two arms are
+    compared with the fp64 chain (dx, dgamma, dbeta) instead of with each other."""
     from nvae_tf_amd import ops
     from nvae_tf_amd.ops import Var
     from nvae_tf_amd.params import ParamStore
+    monkeypatch.setattr(ops, "DW_BNBWD", bnbwd)
     g = torch.Generator().manual_seed(23)
     x = torch.randn(B, H, H, C_, generator=g) * 1.5 + 0.3
     dy = torch.randn(B, H, H, C_, generator=g)
@@ -721,17 +726,22 @@ def test_dwconv5_bn_prologue(lib, dev, monkeypatch, dtype, B, H, C_, act):
             g64, be64 = ps.get("bn.gamma").cpu().double(), ps.get("bn.beta").cpu().double()
     a, b = res["pre"], res["materialised"]
     for k in a:
+        if bnbwd and k in ("dx", "dgamma", "dbeta"):
+            continue                 # (the lazy arm fuses the sums, the materialised arm cannot: compared with fp64 below)
         assert rel_err(a[k], b[k]) < 1e-5, k
     # fp64 chain
     x64 = q(x, dtype).requires_grad_(True)
+    g64 = g64.requires_grad_(True); be64 = be64.requires_grad_(True)
     m = x64.mean((0, 1, 2)); v = x64.var((0, 1, 2), unbiased=False)
     z = (x64 - m) / torch.sqrt(v + 1e-5) * g64 + be64
     hz = z * torch.sigmoid(z) if act else z
     yr = F.conv2d(F.pad(hz.permute(0, 3, 1, 2), (2, 2, 2, 2)), w64.permute(2, 0, 1).unsqueeze(1).contiguous(), b64,
                   groups=C_).permute(0, 2, 3, 1)
-    gx, = torch.autograd.grad(yr, [x64], q(dy, dtype))
+    gx, gg_, gb_ = torch.autograd.grad(yr, [x64, g64, be64], q(dy, dtype))
     tol = TOL[dtype]
     assert rel_err(a["y"], yr) < 2 * tol and rel_err(a["dx"], gx) < 4 * tol
+    for arm in (a, b):
+        assert rel_err(arm["dx"], gx) < 4 * tol and rel_err(arm["dgamma"], gg_) < 4 * tol and rel_err(arm["dbeta"], gb_) < 4 * tol
 
 
 def _softclamp5(x):
