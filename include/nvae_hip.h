@@ -43,7 +43,7 @@ extern "C" {
 
 /* Bumped whenever an entry point is added or a signature changes; the Python binding (nvae_tf_amd/_lib.py
  * ABI_VERSION) refuses to load a library that reports another value. */
-#define NVAE_ABI_VERSION 5
+#define NVAE_ABI_VERSION 6
 
 /* Deterministic mode (NVAE_DETERMINISTIC=1 in the Python host, read by _lib.load()).  With on != 0 every sum across
  * workgroups has ONE adder per address or a fixed order, so the bits a step produces do not depend on workgroup scheduling:

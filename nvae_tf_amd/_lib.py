@@ -13,7 +13,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libnvae_hip.so")
 
-ABI_VERSION = 5          # must equal nvae_abi_version() of the loaded library (include/nvae_hip.h NVAE_ABI_VERSION)
+ABI_VERSION = 6          # must equal nvae_abi_version() of the loaded library (include/nvae_hip.h NVAE_ABI_VERSION)
 F32, BF16, F16 = 0, 1, 2
 ACT_NONE, ACT_SWISH, ACT_ELU = 0, 1, 2
 OP_AFFINE, OP_SWISH, OP_ELU = 0, 1, 2
