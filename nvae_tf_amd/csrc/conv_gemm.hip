@@ -120,7 +120,10 @@ __device__ __forceinline__ void conv_epilogue(f32x4 (&acc)[BM / WM / 16][BN / WN
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const long m = row_m(wm * (BM / WM) + i * 16 + fq * 4 + r);
-                    const ST v = m >= 0 ? (ST)(acc[i][j][r] + bv) : (ST)0;
+                    // (statistics of the OUTPUT: a residual - e.g. the accumulating second GEMM of a concat-free conv - counts)
+                    float o = acc[i][j][r] + bv;
+                    if (residual && m >= 0 && n < N) o += ldf<T>(residual + m * g.res_ld + n);
+                    const ST v = m >= 0 ? (ST)o : (ST)0;
                     s1 += v; s2 += v * v;
                 }
             s1 += __shfl_xor(s1, 16, 64); s1 += __shfl_xor(s1, 32, 64);

@@ -1,6 +1,8 @@
 """Top-down tower, mirroring the reference's decoder.py."""
 from __future__ import annotations
 
+import os
+
 from typing import List
 
 import torch
@@ -9,6 +11,9 @@ from . import _lib as L
 from . import ops
 from .common import Rescaler, RescaleType, Sampler, SqueezeExcitation
 from .ops import Ctx, Var
+
+
+COMBINER_STATS = os.environ.get("NVAE_COMBINER_STATS", "1") != "0"    # the combiner's GEMM emits the next BatchNorm's statistics
 
 
 class DecoderSampleCombiner:
@@ -20,8 +25,13 @@ class DecoderSampleCombiner:
         self.cx, self.cz = x_channels, z_channels
 
     def __call__(self, ctx: Ctx, x: Var, z: Var) -> Var:
-        out = ops.conv2d(ctx, x, self.conv, c_off=0, cin=self.cx)
-        return ops.conv2d(ctx, z, self.conv, c_off=self.cx, cin=self.cz, bias=False, out=out, accumulate=True)
+        # the thin z slice first (direct kernel, carries the bias), then the MFMA GEMM over x accumulates onto it and emits
+        # the BatchNorm statistics of the SUM in its epilogue: the next cell's first BatchNorm needs no statistics pass
+        if not COMBINER_STATS:
+            out = ops.conv2d(ctx, x, self.conv, c_off=0, cin=self.cx)
+            return ops.conv2d(ctx, z, self.conv, c_off=self.cx, cin=self.cz, bias=False, out=out, accumulate=True)
+        out = ops.conv2d(ctx, z, self.conv, c_off=self.cx, cin=self.cz)
+        return ops.conv2d(ctx, x, self.conv, c_off=0, cin=self.cx, bias=False, out=out, accumulate=True, want_stats=True)
 
 
 class GenerativeResidualCell:

@@ -502,7 +502,7 @@ def conv2d(ctx: Ctx, x: Var, conv, *, stride: int = 1, up: int = 1, pad: Optiona
     if fwd_mfma:
         wT = ptr(ps.wcopies) + (conv.wf_off + c_off) * ps.wcopies.element_size()
         slab, fin = None, None
-        if want_stats and ctx.training and not accumulate and out_coff == 0 and Cy == cout:
+        if want_stats and ctx.training and out_coff == 0 and Cy == cout:       # (accumulate / residual: the epilogue counts it in)
             # the conv's epilogue emits the BatchNorm statistics of its output (consumed by bn_act)
             S = lib.nvae_conv_gemm_stats_rows(ctx.dt, C.byref(g))
             slab = ctx.zero_slab(S, cout)      # accumulated into with atomics
