@@ -55,7 +55,8 @@ class Rescaler:
         y = ops.bn_act(ctx, x, self.bn, L.ACT_SWISH)
         if self.mode == RescaleType.UP:
             return ops.conv2d(ctx, y, self.conv, up=self.factor, want_stats=self.feeds_bn, stats_bn=self.stats_bn)
-        return ops.conv2d(ctx, y, self.conv, stride=self.factor)
+        # DOWN (encoder.py:47-57): the next tower's first cell starts with a BatchNorm over this output
+        return ops.conv2d(ctx, y, self.conv, stride=self.factor, want_stats=True)
 
 
 class Sampler:

@@ -92,6 +92,7 @@ class Decoder:
                 c = n_decoder_channels * mult
                 self.groups.append(Rescaler(ps, f"dec.up{scale}", c, c // scale_factor, scale_factor,
                                             RescaleType.UP, in_bn_loss=True))
+                self.groups[-1].feeds_bn = True        # the next scale's first cell starts with a BatchNorm over its output
                 mult //= scale_factor
         self.mult = mult
         self.n_groups = zi
